@@ -1,0 +1,187 @@
+"""NumPy restatement of the reference encoder / decoder graph (TEST ORACLE ONLY).
+
+The reference delegates these ops to Keras/TensorFlow, which cannot be
+installed here, so this file restates their documented semantics; it is
+cross-checked against torch-CPU in tests/test_oracle.py ("parity unpinned" by
+the reference itself -- it ships no tests).  float32 throughout.
+
+Weights container (shared with the product, see wct_tf_amd/weights.py):
+  weights['encoder'][name] = (w_hwio float32 [kh,kw,cin,cout], b float32 [cout])
+     names: 'preprocess' (1x1), 'conv1_1', 'conv1_2', 'conv2_1', ... 'conv5_1'
+  weights['decoder'][relu] = [(w_hwio, b), ...] in execution order
+"""
+import numpy as np
+
+from . import wct_oracle
+
+# VGG19-normalised module order as walked by vgg_normalised.py:22-50
+# ('C' = reflect-pad + 3x3 valid conv + ReLU named relu<name>, 'P' = 2x2 max-pool
+# with padding='same', vgg_normalised.py:42).
+ENCODER_LAYERS = [
+    ('C', 'conv1_1', 3, 64), ('C', 'conv1_2', 64, 64), ('P', 'pool1'),
+    ('C', 'conv2_1', 64, 128), ('C', 'conv2_2', 128, 128), ('P', 'pool2'),
+    ('C', 'conv3_1', 128, 256), ('C', 'conv3_2', 256, 256),
+    ('C', 'conv3_3', 256, 256), ('C', 'conv3_4', 256, 256), ('P', 'pool3'),
+    ('C', 'conv4_1', 256, 512), ('C', 'conv4_2', 512, 512),
+    ('C', 'conv4_3', 512, 512), ('C', 'conv4_4', 512, 512), ('P', 'pool4'),
+    ('C', 'conv5_1', 512, 512),
+]
+
+# model.py:255-277, written as (kind, out_channels)
+DECODER_ARCHS = {
+    5: [('C', 512), ('U',), ('C', 512), ('C', 512), ('C', 512)],
+    4: [('C', 256), ('U',), ('C', 256), ('C', 256), ('C', 256)],
+    3: [('C', 128), ('U',), ('C', 128)],
+    2: [('C', 64), ('U',)],
+    1: [('C', 64)],
+}
+_RELU_NUM = {'relu1_1': 1, 'relu2_1': 2, 'relu3_1': 3, 'relu4_1': 4, 'relu5_1': 5}
+_RELU_CH = {'relu1_1': 64, 'relu2_1': 128, 'relu3_1': 256, 'relu4_1': 512, 'relu5_1': 512}
+
+
+def decoder_layers(relu_target):
+    """Layer list [(kind, cin, cout, relu)] of the decoder for `relu_target`
+    (model.py:283-298: walk decoder_num..1, then a final 3-filter conv with no
+    activation)."""
+    cin = _RELU_CH[relu_target]
+    out = []
+    for d in range(_RELU_NUM[relu_target], 0, -1):
+        for tup in DECODER_ARCHS[d]:
+            if tup[0] == 'C':
+                out.append(('C', cin, tup[1], True))
+                cin = tup[1]
+            else:
+                out.append(('U', cin, cin, False))
+    out.append(('C', cin, 3, False))
+    return out
+
+
+def _pad_reflect(x):
+    """1-px REFLECT pad on H and W (edge not repeated), ops.py:12-15."""
+    return np.pad(x, ((1, 1), (1, 1), (0, 0)), mode='reflect')
+
+
+def conv3x3_reflect(x, w_hwio, b, relu=True):
+    """Reflect-pad(1) + 3x3 VALID conv + bias (+ReLU); ops.py:17-19,
+    vgg_normalised.py:28-40.  x: HxWxCin float32; w: 3x3xCinxCout."""
+    x = np.asarray(x, np.float32)
+    h, w, cin = x.shape
+    cout = w_hwio.shape[3]
+    xp = _pad_reflect(x)
+    wmat = np.ascontiguousarray(w_hwio, np.float32).reshape(9 * cin, cout)
+    out = np.empty((h, w, cout), np.float32)
+    rows = max(1, (1 << 22) // max(1, w * 9 * cin))  # bound the im2col strip
+    for r0 in range(0, h, rows):
+        r1 = min(h, r0 + rows)
+        cols = np.empty((r1 - r0, w, 9, cin), np.float32)
+        for ky in range(3):
+            for kx in range(3):
+                cols[:, :, ky * 3 + kx, :] = xp[r0 + ky:r1 + ky, kx:kx + w, :]
+        o = cols.reshape(-1, 9 * cin) @ wmat
+        out[r0:r1] = o.reshape(r1 - r0, w, cout)
+    out += np.asarray(b, np.float32)
+    if relu:
+        np.maximum(out, 0, out=out)
+    return out
+
+
+def conv1x1(x, w_hwio, b):
+    """The VGG 'preprocess' 1x1 conv (vgg_normalised.py:25-26,28-38)."""
+    cin = w_hwio.shape[2]
+    return (np.asarray(x, np.float32).reshape(-1, cin) @ w_hwio.reshape(cin, -1)
+            ).reshape(x.shape[0], x.shape[1], -1) + np.asarray(b, np.float32)
+
+
+def maxpool2x2_same(x):
+    """MaxPooling2D(pool 2, stride 2, padding='same') == ceil-mode pooling:
+    the odd last row/col pools over the cells that exist (vgg_normalised.py:42)."""
+    h, w, c = x.shape
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    xp = np.full((ho * 2, wo * 2, c), -np.inf, np.float32)
+    xp[:h, :w] = x
+    return xp.reshape(ho, 2, wo, 2, c).max(axis=(1, 3))
+
+
+def upsample2x_nearest(x):
+    """UpSampling2D() default: x2 nearest (model.py:293)."""
+    return np.repeat(np.repeat(x, 2, axis=0), 2, axis=1)
+
+
+def encode(img01, weights, targets):
+    """Run the shared VGG on an HxWx3 image in [0,1]; return {relu: features}
+    for every relu name in `targets` (model.py:60-75,135-139)."""
+    enc = weights['encoder']
+    want = set(targets)
+    deepest = sorted(want)[-1]                       # model.py:60
+    x = conv1x1(np.asarray(img01, np.float32), *enc['preprocess'])
+    feats = {}
+    for layer in ENCODER_LAYERS:
+        if layer[0] == 'C':
+            name = layer[1]
+            x = conv3x3_reflect(x, enc[name][0], enc[name][1], relu=True)
+            relu = 'relu' + name[4:]
+            if relu in want:
+                feats[relu] = x
+            if relu == deepest:
+                break
+        else:
+            x = maxpool2x2_same(x)
+    return feats
+
+
+def decode(feat, weights, relu_target):
+    """Mirror decoder for `relu_target` (model.py:245-304)."""
+    x = np.asarray(feat, np.float32)
+    params = weights['decoder'][relu_target]
+    i = 0
+    for kind, cin, cout, relu in decoder_layers(relu_target):
+        if kind == 'C':
+            w, b = params[i]
+            i += 1
+            x = conv3x3_reflect(x, w, b, relu=relu)
+        else:
+            x = upsample2x_nearest(x)
+    return x
+
+
+def preprocess(image):
+    """wct.py:60-64 (batch dim dropped: the oracle works on HxWx3)."""
+    return np.asarray(image, np.float64) / 255.
+
+
+def postprocess(image01):
+    """wct.py:66-68: clip to [0,1], *255, truncate to uint8."""
+    return np.uint8(np.clip(image01, 0, 1) * 255)
+
+
+def stylize(content, style, weights, relu_targets, alpha=1.0, adain=False,
+            wct_mode='tf', return_levels=False):
+    """One WCT.predict (wct.py:70-106) through the test-mode graph
+    (model.py:33-94,123-176): ONE style pass with all taps; levels in
+    `relu_targets` order; level i>0 encodes clip(previous decoded, 0, 1)
+    (model.py:86); output = last decoded, postprocessed.
+
+    wct_mode 'tf' is what the live graph runs (wct_tf, model.py:154,158);
+    'np' swaps in the wct_np semantics the north star names as oracle.
+    """
+    c01 = np.float32(preprocess(content))
+    s01 = np.float32(preprocess(style))
+    style_feats = encode(s01, weights, relu_targets)
+    x = c01
+    levels = []
+    for i, relu in enumerate(relu_targets):
+        if i > 0:
+            x = np.clip(x, 0, 1)
+        fc = encode(x, weights, [relu])[relu]
+        fs = style_feats[relu]
+        if adain:
+            t = wct_oracle.adain(fc, fs, alpha)[0]
+        elif wct_mode == 'tf':
+            t = wct_oracle.wct_tf(fc, fs, alpha)[0]
+        else:
+            t = wct_oracle.wct_np(fc, fs, alpha)[0]
+        x = decode(t, weights, relu)
+        if return_levels:
+            levels.append((fc, fs, t, x))
+    out = postprocess(x)
+    return (out, levels) if return_levels else out

@@ -1,0 +1,156 @@
+"""NumPy restatement of the reference feature transforms (TEST ORACLE ONLY).
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).  Nothing here is imported by the product path.
+"""
+import numpy as np
+
+
+def _flatten_chw(feat):
+    """1xHxWxC (or HxWxC) -> (C, H*W), channel-major, as ops.py:98-103 does."""
+    f = np.squeeze(feat)
+    if f.ndim != 3:
+        raise ValueError("expected a single HxWxC feature map")
+    h, w, c = f.shape
+    return np.transpose(f, (2, 0, 1)).reshape(c, h * w), (h, w, c)
+
+
+def _unflatten(mat, shape):
+    h, w, c = shape
+    return np.transpose(mat.reshape(c, h, w), (1, 2, 0))[None]
+
+
+def wct_np(content, style, alpha=0.6, eps=1e-5):
+    """Whiten-colour transform, NumPy semantics of ops.py:92-140.
+
+    * no eps on the covariance (ops.py:108,121)
+    * keep singular values > 1e-5 (ops.py:112,125)
+    * D_c = (w+eps)^-1/2 (ops.py:114), D_s = sqrt(w+eps) (ops.py:127)
+    * blend alpha*fcs + (1-alpha)*fc : the content mean is NOT restored
+      (ops.py:133)
+    * result cast to float32 (ops.py:140); arithmetic dtype follows the input.
+    """
+    fc_full, cshape = _flatten_chw(content)
+    fs_full, _ = _flatten_chw(style)
+    nc = fc_full.shape[1]
+    ns = fs_full.shape[1]
+
+    mc = fc_full.mean(axis=1, keepdims=True)
+    fc = fc_full - mc
+    cov_c = np.dot(fc, fc.T) / (nc - 1)
+    ec, wc, _ = np.linalg.svd(cov_c)
+    kc = int((wc > 1e-5).sum())
+    dc = np.diag((wc[:kc] + eps) ** -0.5)
+    whitened = ec[:, :kc].dot(dc).dot(ec[:, :kc].T).dot(fc)
+
+    ms = fs_full.mean(axis=1, keepdims=True)
+    fs = fs_full - ms
+    cov_s = np.dot(fs, fs.T) / (ns - 1)
+    es, ws, _ = np.linalg.svd(cov_s)
+    ks = int((ws > 1e-5).sum())
+    ds = np.sqrt(np.diag(ws[:ks] + eps))
+    colored = es[:, :ks].dot(ds).dot(es[:, :ks].T).dot(whitened) + ms
+
+    blended = alpha * colored + (1 - alpha) * fc
+    return np.float32(_unflatten(blended, cshape))
+
+
+def wct_tf(content, style, alpha, eps=1e-8):
+    """Whiten-colour transform, TensorFlow-graph semantics of ops.py:24-90.
+
+    * eps*I added to both covariances (ops.py:45,50)
+    * keep singular values > 1e-5 (ops.py:68-69)
+    * D_c = S^-1/2 with no eps (ops.py:72), D_s = S^1/2 (ops.py:76)
+    * blend alpha*fcs + (1-alpha)*(fc + mc) : content mean restored (ops.py:83)
+    Computed in float32 like the TF graph.
+    """
+    fc_full, cshape = _flatten_chw(np.asarray(content, np.float32))
+    fs_full, _ = _flatten_chw(np.asarray(style, np.float32))
+    c = fc_full.shape[0]
+    nc = fc_full.shape[1]
+    ns = fs_full.shape[1]
+    eye = np.eye(c, dtype=np.float32)
+
+    mc = fc_full.mean(axis=1, keepdims=True)
+    fc = fc_full - mc
+    cov_c = np.dot(fc, fc.T) / np.float32(nc - 1.0) + eye * np.float32(eps)
+    ms = fs_full.mean(axis=1, keepdims=True)
+    fs = fs_full - ms
+    cov_s = np.dot(fs, fs.T) / np.float32(ns - 1.0) + eye * np.float32(eps)
+
+    uc, sc, _ = np.linalg.svd(cov_c)
+    us, ss, _ = np.linalg.svd(cov_s)
+    kc = int((sc > 1e-5).sum())
+    ks = int((ss > 1e-5).sum())
+
+    dc = np.diag(sc[:kc] ** np.float32(-0.5))
+    whitened = uc[:, :kc].dot(dc).dot(uc[:, :kc].T).dot(fc)
+    ds = np.diag(ss[:ks] ** np.float32(0.5))
+    colored = us[:, :ks].dot(ds).dot(us[:, :ks].T).dot(whitened) + ms
+
+    blended = np.float32(alpha) * colored + np.float32(1 - alpha) * (fc + mc)
+    return np.float32(_unflatten(blended, cshape))
+
+
+def adain(content_features, style_features, alpha, epsilon=1e-5):
+    """AdaIN, semantics of ops.py:282-294.
+
+    tf.nn.moments over H,W gives the POPULATION variance; batch_normalization is
+    (x - mean) * rsqrt(var + eps) * scale + offset with scale = sqrt(style var)
+    (no eps on the style side) and offset = style mean; then alpha-blend with
+    the un-normalised content features.
+    """
+    x = np.asarray(content_features, np.float32)
+    s = np.asarray(style_features, np.float32)
+    if x.ndim == 3:
+        x = x[None]
+    if s.ndim == 3:
+        s = s[None]
+    mu_s = s.mean(axis=(1, 2), keepdims=True)
+    var_s = s.var(axis=(1, 2), keepdims=True)
+    mu_c = x.mean(axis=(1, 2), keepdims=True)
+    var_c = x.var(axis=(1, 2), keepdims=True)
+    inv = 1.0 / np.sqrt(var_c + np.float32(epsilon))
+    y = (x - mu_c) * inv * np.sqrt(var_s) + mu_s
+    return np.float32(np.float32(alpha) * y + np.float32(1 - alpha) * x)
+
+
+def mat_sqrt_numpy(x):
+    """Matrix square root through the SVD, coral.py:8-11."""
+    u, d, vt = np.linalg.svd(x)
+    # the reference multiplies by V.T where V is numpy's third return value
+    # (already V^H), i.e. it uses vt.T -- reproduced literally (coral.py:10).
+    return u.dot(np.diag(np.sqrt(d))).dot(vt.T)
+
+
+def coral_numpy(source, target):
+    """CORAL colour alignment of `source` to `target`, coral.py:13-39.
+
+    Per-channel standardise (population std), cov = X X^T + I (NOT divided by
+    N), transfer = sqrt(Ct) . inv(sqrt(Cs)) . Xs, de-normalise with the target
+    statistics.  dtype follows the inputs (float64 from `img/255.`).
+    """
+    c = source.shape[-1]
+    src = np.moveaxis(source, -1, 0).reshape(c, -1)
+    tgt = np.moveaxis(target, -1, 0).reshape(c, -1)
+
+    src_mean = src.mean(axis=1, keepdims=True)
+    src_std = src.std(axis=1, keepdims=True)
+    src_n = (src - src_mean) / src_std
+    tgt_mean = tgt.mean(axis=1, keepdims=True)
+    tgt_std = tgt.std(axis=1, keepdims=True)
+    tgt_n = (tgt - tgt_mean) / tgt_std
+
+    cov_s = src_n.dot(src_n.T) + np.eye(c)
+    cov_t = tgt_n.dot(tgt_n.T) + np.eye(c)
+
+    xfer = mat_sqrt_numpy(cov_t).dot(np.linalg.inv(mat_sqrt_numpy(cov_s))).dot(src_n)
+    out = xfer * tgt_std + tgt_mean
+    h, w = source.shape[0], source.shape[1]
+    return np.moveaxis(out.reshape(c, h, w), 0, -1)
+
+
+def preserve_colors_np(style_rgb, content_rgb):
+    """utils.py:87-90: CORAL on [0,1] images, clip, truncate to uint8."""
+    coraled = coral_numpy(style_rgb / 255., content_rgb / 255.)
+    return np.uint8(np.clip(coraled, 0, 1) * 255.)

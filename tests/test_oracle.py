@@ -1,0 +1,141 @@
+"""Pin the oracle: against outputs of the reference's own functions
+(tests/golden, made by oracle/make_golden.py) and against an independent
+torch-CPU implementation for the ops the reference delegates to TF/Keras."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from conftest import GOLDEN, rel_err, max_rel
+from wct_tf_amd.weights import (synthetic_weights, synthetic_features, synthetic_image,
+                                decoder_plan)
+
+
+def _cases(fname):
+    z = np.load(os.path.join(GOLDEN, fname))
+    names = sorted({k.split('/')[0] for k in z.files})
+    return z, names
+
+
+def test_wct_np_matches_reference_outputs():
+    z, names = _cases('wct_np_reference.npz')
+    assert len(names) >= 5
+    for n in names:
+        alpha = float(z[n + '/alpha'])
+        args = () if alpha < 0 else (alpha,)
+        got = oracle.wct_np(z[n + '/content'], z[n + '/style'], *args)
+        ref = z[n + '/out']
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        # same LAPACK, same op order: should agree to fp32 round-off
+        assert rel_err(got, ref) < 1e-5, n
+        assert max_rel(got, ref) < 1e-4, n
+
+
+def test_coral_matches_reference_outputs():
+    z, names = _cases('coral_reference.npz')
+    for n in names:
+        src, tgt = z[n + '/source'], z[n + '/target']
+        got = oracle.coral_numpy(src / 255., tgt / 255.)
+        assert rel_err(got, z[n + '/coral']) < 1e-10
+        assert np.array_equal(oracle.preserve_colors_np(src, tgt), z[n + '/preserve'])
+
+
+def test_wct_properties_alpha1_matches_style_statistics():
+    # alpha=1, full rank: output mean = style mean, covariance ~= style covariance
+    fc = synthetic_features(1, 32, 24, 24, 2.0)
+    fs = synthetic_features(2, 32, 20, 28, 2.0)
+    for fn in (lambda: oracle.wct_np(fc, fs, 1.0), lambda: oracle.wct_tf(fc, fs, 1.0)):
+        out = fn().reshape(-1, 32).astype(np.float64)
+        s = fs.reshape(-1, 32).astype(np.float64)
+        assert np.allclose(out.mean(0), s.mean(0), atol=1e-3)
+        cov_o = np.cov(out.T)
+        cov_s = np.cov(s.T)
+        assert rel_err(cov_o, cov_s) < 2e-2
+
+
+def test_wct_tf_vs_np_semantics_differ_only_as_documented():
+    fc = synthetic_features(3, 32, 16, 16, 2.0)
+    fs = synthetic_features(4, 32, 16, 16, 2.0)
+    a = 0.7
+    tf_ = oracle.wct_tf(fc, fs, a)
+    np_ = oracle.wct_np(fc, fs, a)
+    mc = fc.reshape(-1, 32).mean(0)
+    # np mode drops (1-alpha)*mc (ops.py:133 vs ops.py:83); eps differences are tiny here
+    assert rel_err(tf_ - (1 - a) * mc, np_) < 5e-3
+
+
+def test_adain_statistics():
+    fc = synthetic_features(5, 16, 12, 12, 1.0)
+    fs = synthetic_features(6, 16, 10, 14, 1.0)
+    out = oracle.adain(fc, fs, 1.0)[0].reshape(-1, 16)
+    s = fs.reshape(-1, 16)
+    assert np.allclose(out.mean(0), s.mean(0), atol=1e-4)
+    assert np.allclose(out.std(0), s.std(0), rtol=2e-2, atol=1e-3)
+
+
+def _torch_conv(x, w, b, relu):
+    t = torch.from_numpy(x.transpose(2, 0, 1)[None])
+    t = F.pad(t, (1, 1, 1, 1), mode='reflect')
+    wt = torch.from_numpy(np.ascontiguousarray(w.transpose(3, 2, 0, 1)))
+    y = F.conv2d(t, wt, torch.from_numpy(b))
+    if relu:
+        y = F.relu(y)
+    return y[0].permute(1, 2, 0).numpy()
+
+
+def test_conv_pool_upsample_match_torch():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((13, 10, 8)).astype(np.float32)
+    w = rng.standard_normal((3, 3, 8, 16)).astype(np.float32)
+    b = rng.standard_normal(16).astype(np.float32)
+    for relu in (True, False):
+        assert rel_err(oracle.conv3x3_reflect(x, w, b, relu), _torch_conv(x, w, b, relu)) < 1e-5
+    t = torch.from_numpy(x.transpose(2, 0, 1)[None])
+    p = F.max_pool2d(t, 2, 2, ceil_mode=True)[0].permute(1, 2, 0).numpy()
+    assert np.array_equal(oracle.maxpool2x2_same(x), p)
+    u = F.interpolate(t, scale_factor=2, mode='nearest')[0].permute(1, 2, 0).numpy()
+    assert np.array_equal(oracle.upsample2x_nearest(x), u)
+
+
+def test_decoder_plan_matches_oracle_and_survey_counts():
+    counts = {'relu5_1': 13, 'relu4_1': 9, 'relu3_1': 5, 'relu2_1': 3, 'relu1_1': 2}
+    for relu, n in counts.items():
+        assert decoder_plan(relu) == oracle.decoder_layers(relu)
+        assert sum(1 for p in decoder_plan(relu) if p[0] == 'C') == n
+
+
+def test_encoder_decoder_match_torch_small():
+    w = synthetic_weights(relu_targets=['relu3_1'])
+    img = synthetic_image(11, 36, 28)          # not a multiple of 4: exercises ceil pooling
+    feats = oracle.encode(np.float32(img / 255.), w, ['relu3_1', 'relu1_1'])
+    assert feats['relu1_1'].shape == (36, 28, 64)
+    assert feats['relu3_1'].shape == (9, 7, 256)
+    # independent torch re-run of the same chain
+    x = np.float32(img / 255.) @ w['encoder']['preprocess'][0].reshape(3, 3) + w['encoder']['preprocess'][1]
+    for kind, *rest in oracle.ENCODER_LAYERS:
+        if kind == 'C':
+            name = rest[0]
+            x = _torch_conv(x.astype(np.float32), *w['encoder'][name], True)
+            if name == 'conv3_1':
+                break
+        else:
+            t = torch.from_numpy(x.transpose(2, 0, 1)[None])
+            x = F.max_pool2d(t, 2, 2, ceil_mode=True)[0].permute(1, 2, 0).numpy()
+    assert rel_err(feats['relu3_1'], x) < 1e-4
+    dec = oracle.decode(feats['relu3_1'], w, 'relu3_1')
+    assert dec.shape == (36, 28, 3)
+
+
+def test_stylize_pipeline_shapes_and_chaining():
+    targets = ['relu2_1', 'relu1_1']
+    w = synthetic_weights(relu_targets=targets)
+    c = synthetic_image(1000, 32, 48)
+    s = synthetic_image(2000, 40, 24)
+    out, levels = oracle.stylize(c, s, w, targets, alpha=0.8, return_levels=True)
+    assert out.dtype == np.uint8 and out.shape == (32, 48, 3)
+    assert levels[0][0].shape == (16, 24, 128) and levels[0][1].shape == (20, 12, 128)
+    out_adain = oracle.stylize(c, s, w, targets, alpha=0.8, adain=True)
+    assert out_adain.shape == out.shape and not np.array_equal(out, out_adain)
