@@ -1,0 +1,137 @@
+/* libwct_hip.so -- C ABI of the MI355X (gfx950) stylize hot path.
+ *
+ * The reference (eridgd/WCT-TF) has no FFI: its boundary is the Python API that
+ * drives one TensorFlow session.  Each entry point below names the reference
+ * interface it replaces (paths relative to the reference tree).  INTEGRATION.md
+ * shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative wct_status on failure;
+ *     wct_last_error() returns a thread-local message.  No exceptions cross the ABI.
+ *   - one wct_ctx = one GPU + one HIP stream; calls on a ctx are serialised
+ *     (the reference's predict() is blocking and not re-entrant, wct.py:70-106);
+ *     distinct contexts are independent (one per process/GPU for multi-GPU).
+ *   - "host" pointers are caller-owned and only read/written during the call;
+ *     "dev" pointers are device memory obtained from wct_dev_alloc (or any
+ *     hipMalloc'ed / torch CUDA pointer on the same device).
+ *   - images: uint8 HxWx3 RGB, row-major (wct.py:60-68).  features: float32
+ *     NHWC with batch 1, i.e. [H*W][C] pixel-major (ops.py:32-33 squeeze).
+ *   - weights: float32 HWIO, exactly what vgg_normalised.py:33 / Keras Conv2D hold.
+ */
+#ifndef WCT_HIP_H
+#define WCT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wct_ctx wct_ctx;
+
+enum wct_status { WCT_STATUS_OK = 0, WCT_STATUS_HIP = -1, WCT_STATUS_ARG = -2,
+                  WCT_STATUS_STATE = -3, WCT_STATUS_NOMEM = -4 };
+
+/* transform semantics: wct_np (ops.py:92-140) or the live-graph wct_tf (ops.py:24-90) */
+enum wct_mode { WCT_NP = 0, WCT_TF = 1 };
+
+/* flags for wct_stylize* */
+enum wct_flags {
+  WCT_FLAG_ADAIN = 1,      /* --adain: AdaIN at every level instead of WCT (model.py:148-158) */
+  WCT_FLAG_MODE_NP = 2     /* use wct_np semantics instead of the graph's wct_tf */
+};
+
+/* ---- lifecycle: replaces WCT.__init__'s tf.Session setup (wct.py:29-44) ---- */
+int  wct_create(int device, wct_ctx** out);
+void wct_destroy(wct_ctx* ctx);
+const char* wct_last_error(void);
+int  wct_sync(wct_ctx* ctx);                       /* block until the ctx stream is idle */
+int  wct_device_count(int* n);
+
+/* ---- weights: replace vgg_from_t7 (vgg_normalised.py:10-55) and the per-decoder
+ * Saver.restore (wct.py:46-58).  The library copies, folds the 1x1 'preprocess'
+ * into conv1_1 and repacks to its fp16 [Cout][tap][Cin] layout.
+ *   pre_w [3][3] (in,out) and pre_b [3]: the 1x1 preprocess conv;
+ *   w[i] HWIO 3x3 and b[i] for conv1_1, conv1_2, conv2_1, conv2_2, conv3_1..3_4,
+ *   conv4_1..4_4, conv5_1 (13 layers). */
+int wct_set_encoder(wct_ctx* ctx, const float* pre_w, const float* pre_b,
+                    const float* const* w, const float* const* b, int n_layers);
+/* decoder for relu<level>_1, level 1..5; conv layers in execution order
+ * (model.py:283-298): 2, 3, 5, 9, 13 layers for level 1..5. */
+int wct_set_decoder(wct_ctx* ctx, int level, const float* const* w, const float* const* b,
+                    int n_layers);
+
+/* ---- op level (host pointers), for parity tests -------------------------------- */
+/* wct_np / wct_tf (ops.py:24-140): content [Nc][C], style [Ns][C], out [Nc][C].
+ * eps: the reference functions' `eps` argument (wct_np: added inside the spectral gains,
+ * default 1e-5; wct_tf: added to the covariance diagonal, default 1e-8); eps < 0 = default. */
+int wct_transform(wct_ctx* ctx, const float* content, int Nc, const float* style, int Ns,
+                  int C, float alpha, int mode, float eps, float* out,
+                  int* sweeps_out /* [2] or NULL */);
+/* adain (ops.py:282-294), epsilon as in the reference signature */
+int wct_adain(wct_ctx* ctx, const float* content, int Nc, const float* style, int Ns,
+              int C, float alpha, float epsilon, float* out);
+/* symmetric eigendecomposition used in place of tf.svd / np.linalg.svd (ops.py:53-55,110,123):
+ * A [nmat][C][C] in; evals [nmat][C], evecs [nmat][C][C] (columns) out. */
+int wct_eigh(wct_ctx* ctx, const float* A, int C, int nmat, float* evals, float* evecs,
+             int* sweeps_out /* [nmat] or NULL */);
+/* Conv2DReflect (ops.py:17-19): x [H][W][Cin] fp32, w HWIO, y [Ho][Wo][Cout] fp32;
+ * upsample!=0 applies UpSampling2D x2 first (model.py:293). fp16 operands, fp32 accumulate. */
+int wct_conv3x3(wct_ctx* ctx, const float* x, int H, int W, int Cin, const float* w_hwio,
+                const float* bias, int Cout, int relu, int upsample, float* y);
+/* MaxPooling2D(padding='same') (vgg_normalised.py:42): y [(H+1)/2][(W+1)/2][C] */
+int wct_maxpool(wct_ctx* ctx, const float* x, int H, int W, int C, float* y);
+/* encoder to relu<level>_1 (model.py:135-139): img01 [H][W][3] in [0,1]; feat [h][w][C] */
+int wct_encode(wct_ctx* ctx, const float* img01, int H, int W, int level, float* feat);
+/* decoder for relu<level>_1 (model.py:245-304): feat [h][w][C]; img [h*2^(l-1)][w*2^(l-1)][3] */
+int wct_decode(wct_ctx* ctx, const float* feat, int h, int w, int level, float* img);
+/* coral_numpy / preserve_colors_np (coral.py:13-39, utils.py:87-90), the O(pixels) parts:
+ *   wct_coral_stats: exact integer moments of a uint8 image on the GPU:
+ *     sums[0..2] = sum_c x, sums[3..8] = sum x_i x_j for (i,j) = 00,01,02,11,12,22.
+ *   wct_coral_apply: out = (M ((x/255 - src_mean)/src_std)) * tgt_std + tgt_mean in float64,
+ *     and its clip/x255/truncate uint8 image (utils.py:89).  Either output may be NULL.
+ * The 3x3 step between them (coral.py:30-33: X X^T + I, matSqrt through the SVD, inverse) stays on
+ * the host in the caller: the reference's matSqrt multiplies U sqrt(D) by U -- not U^T -- so its
+ * value is defined by LAPACK's singular-vector signs, and only LAPACK reproduces that. */
+int wct_coral_stats(wct_ctx* ctx, const uint8_t* img, int H, int W, double sums[9]);
+int wct_coral_apply(wct_ctx* ctx, const uint8_t* src, int H, int W, const double M[9],
+                    const double src_mean[3], const double src_std[3],
+                    const double tgt_mean[3], const double tgt_std[3],
+                    uint8_t* out_u8, double* out_f64);
+
+/* ---- the hot path: WCT.predict (wct.py:70-106) -------------------------------------
+ * levels: relu levels in pipeline order, e.g. {5,4,3,2,1}.  Output size: wct_output_size. */
+int wct_output_size(int Hc, int Wc, const int* levels, int n_levels, int* Ho, int* Wo);
+int wct_stylize(wct_ctx* ctx, const uint8_t* content, int Hc, int Wc,
+                const uint8_t* style, int Hs, int Ws,
+                const int* levels, int n_levels, float alpha, unsigned flags,
+                uint8_t* out);
+/* batched, device-resident variant: B independent pairs (same sizes), content [B][Hc][Wc][3],
+ * style [B][Hs][Ws][3], out [B][Ho][Wo][3], all device pointers; asynchronous on the ctx
+ * stream (call wct_sync).  This is what bench.py times. */
+int wct_stylize_batch_dev(wct_ctx* ctx, const uint8_t* content_dev, int Hc, int Wc,
+                          const uint8_t* style_dev, int Hs, int Ws, int B,
+                          const int* levels, int n_levels, float alpha, unsigned flags,
+                          uint8_t* out_dev);
+
+/* ---- device memory helpers (thin wrappers so callers need no HIP binding) ----------- */
+int wct_dev_alloc(wct_ctx* ctx, size_t bytes, void** out);
+int wct_dev_free(wct_ctx* ctx, void* p);
+int wct_h2d(wct_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int wct_d2h(wct_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- measurement: per-kernel-class HIP-event timing on the ctx stream ----------------
+ * class ids: 0 conv3x3 (MFMA), 1 conv_first, 2 conv_last, 3 pool, 4 wct stats+cov,
+ * 5 jacobi eigensolver, 6 wct tbuild+apply, 7 other.  When enabled every launch group is
+ * bracketed by hipEventRecord on the ctx stream; wct_prof_read syncs and accumulates. */
+#define WCT_PROF_CLASSES 8
+int wct_prof_enable(wct_ctx* ctx, int on);
+int wct_prof_reset(wct_ctx* ctx);
+int wct_prof_read(wct_ctx* ctx, double ms[WCT_PROF_CLASSES], long long launches[WCT_PROF_CLASSES],
+                  double flops[WCT_PROF_CLASSES], double bytes[WCT_PROF_CLASSES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCT_HIP_H */

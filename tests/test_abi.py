@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the library builds for gfx950, loads, and
+exports every symbol include/wct_hip.h declares; host-side logic (descriptors, facade
+errors) behaves like the reference's."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from wct_tf_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    from wct_tf_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'wct_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)          # drop comments
+    declared = set(re.findall(r'^\s*(?:int|void|const char\*)\s+(wct_[a-z0-9_]+)\s*\(', header, re.M))
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_errors_cross_the_abi_as_status_codes(lib):
+    import ctypes as C
+    from wct_tf_amd import _lib
+    rc = lib.wct_sync(None)
+    assert rc == -2 and b'invalid argument' in lib.wct_last_error()
+    ho, wo = C.c_int(), C.c_int()
+    lv = (C.c_int * 5)(5, 4, 3, 2, 1)
+    assert lib.wct_output_size(500, 500, lv, 5, C.byref(ho), C.byref(wo)) == 0
+    assert (ho.value, wo.value) == (512, 512)          # 500 -> ceil-pooled 32 -> x16 = 512
+    assert lib.wct_output_size(512, 384, lv, 5, C.byref(ho), C.byref(wo)) == 0
+    assert (ho.value, wo.value) == (512, 384)
+    bad = (C.c_int * 1)(7)
+    assert lib.wct_output_size(64, 64, bad, 1, C.byref(ho), C.byref(wo)) == -2
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from wct_tf_amd.context import Context
+    from wct_tf_amd._lib import WCTHipError
+    with pytest.raises(WCTHipError):
+        Context(0)
+
+
+def test_model_descriptor_mirrors_reference_attributes():
+    from wct_tf_amd import WCTModel
+    m = WCTModel(mode='test', relu_targets=['relu3_1', 'relu1_1'])
+    for attr in ('content_input', 'style_input', 'alpha', 'swap5', 'ss_alpha', 'use_adain',
+                 'decoded_output', 'encoder_decoders', 'vgg_model'):
+        assert hasattr(m, attr)
+    assert m.deepest_target == 'relu3_1' and len(m.encoder_decoders) == 2
+    assert m.encoder_decoders[1].content_input == 'clip(relu3_1.decoded)'
+    with pytest.raises(NotImplementedError):
+        WCTModel(mode='train')
+
+
+def test_weights_roundtrip(tmp_path):
+    from wct_tf_amd.weights import synthetic_weights, save_weights, load_weights
+    w = synthetic_weights(relu_targets=['relu2_1'])
+    p = str(tmp_path / 'w.npz')
+    save_weights(p, w)
+    r = load_weights(p)
+    assert set(r['encoder']) == set(w['encoder'])
+    assert np.array_equal(r['decoder']['relu2_1'][2][0], w['decoder']['relu2_1'][2][0])
+    assert np.array_equal(r['encoder']['conv3_1'][1], w['encoder']['conv3_1'][1])
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'wct_tf_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f

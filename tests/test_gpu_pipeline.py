@@ -1,0 +1,136 @@
+"""GPU parity tests, layer and pipeline level (encoder, decoders, WCT.predict)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import rel_err, max_rel
+from wct_tf_amd.weights import synthetic_weights, synthetic_image, RELU_TARGETS
+
+pytestmark = pytest.mark.gpu
+
+# fp16 activations through up to 13 stacked convs
+ENC_TOL = 1e-2
+
+
+@pytest.fixture(scope='module')
+def weights():
+    return synthetic_weights(seed=42)
+
+
+@pytest.fixture(scope='module')
+def ctx(weights):
+    from wct_tf_amd.context import Context
+    c = Context(0)
+    c.set_weights(weights)
+    yield c
+    c.close()
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.parametrize('size', [(64, 64), (72, 56)])
+def test_encoder_all_levels(ctx, weights, size):
+    img = np.float32(synthetic_image(7, *size) / 255.)
+    want = oracle.encode(img, weights, RELU_TARGETS)
+    for relu in RELU_TARGETS:
+        got = ctx.encode(img, relu)
+        e = rel_err(got, want[relu])
+        print(size, relu, got.shape, 'rel %.2e' % e)
+        assert got.shape == want[relu].shape
+        assert e < ENC_TOL
+
+
+@pytest.mark.parametrize('relu,hw', [('relu1_1', (32, 24)), ('relu2_1', (16, 16)), ('relu3_1', (8, 12)),
+                                     ('relu4_1', (4, 4)), ('relu5_1', (3, 2))])
+def test_decoders(ctx, weights, relu, hw):
+    from wct_tf_amd.weights import RELU_CHANNELS
+    rng = np.random.default_rng(11)
+    feat = np.maximum(rng.standard_normal((hw[0], hw[1], RELU_CHANNELS[relu])), 0).astype(np.float32)
+    got = ctx.decode(feat, relu)
+    want = oracle.decode(feat, weights, relu)
+    e = rel_err(got, want)
+    print(relu, got.shape, 'rel %.2e' % e, 'max abs %.3e' % np.abs(got - want).max())
+    assert got.shape == want.shape and e < ENC_TOL
+
+
+def _teacher_forced(ctx, weights, content, style, targets, alpha, mode):
+    """Run the oracle pipeline; feed each level's oracle inputs to the GPU ops and compare."""
+    from wct_tf_amd import _lib
+    out, levels = oracle.stylize(content, style, weights, targets, alpha=alpha, wct_mode=mode, return_levels=True)
+    for relu, (fc, fs, t, x) in zip(targets, levels):
+        c = fc.shape[-1]
+        got_t = ctx.transform(fc.reshape(-1, c), fs.reshape(-1, c), alpha,
+                              _lib.WCT_TF if mode == 'tf' else _lib.WCT_NP).reshape(t.shape)
+        e = rel_err(got_t, t)
+        print(relu, 'transform rel %.2e' % e)
+        assert e < 1e-3
+        got_x = ctx.decode(t, relu)
+        assert rel_err(got_x, x) < ENC_TOL
+    return out
+
+
+def test_pipeline_two_levels_teacher_forced_and_end_to_end(ctx, weights):
+    targets = ['relu2_1', 'relu1_1']
+    c = synthetic_image(1000, 64, 80)
+    s = synthetic_image(2000, 72, 56)
+    want = _teacher_forced(ctx, weights, c, s, targets, 0.8, 'tf')
+    got = ctx.stylize(c, s, targets, alpha=0.8)
+    d = np.abs(got.astype(int) - want.astype(int))
+    print('2-level end-to-end: psnr %.1f dB, max LSB %d, mean LSB %.3f' % (psnr(got, want), d.max(), d.mean()))
+    assert got.shape == want.shape and psnr(got, want) > 35
+
+
+def test_pipeline_five_levels_end_to_end(ctx, weights):
+    c = synthetic_image(1000, 128, 128)
+    s = synthetic_image(2000, 128, 128)
+    for mode in ('tf', 'np'):
+        want = _teacher_forced(ctx, weights, c, s, RELU_TARGETS, 0.8, mode)
+        got = ctx.stylize(c, s, RELU_TARGETS, alpha=0.8, wct_mode=mode)
+        d = np.abs(got.astype(int) - want.astype(int))
+        print('5-level %s: psnr %.1f dB, max LSB %d, mean LSB %.3f' % (mode, psnr(got, want), d.max(), d.mean()))
+        assert got.shape == want.shape and psnr(got, want) > 30
+
+
+def test_pipeline_adain_and_odd_sizes(ctx, weights):
+    targets = ['relu3_1', 'relu1_1']
+    c = synthetic_image(1001, 50, 70)           # not multiples of 4: ceil pooling + x2 upsampling grow the frame
+    s = synthetic_image(2001, 64, 64)
+    want = oracle.stylize(c, s, weights, targets, alpha=0.6, adain=True)
+    got = ctx.stylize(c, s, targets, alpha=0.6, adain=True)
+    assert got.shape == want.shape == (52, 72, 3)
+    print('adain odd: psnr %.1f' % psnr(got, want))
+    assert psnr(got, want) > 35
+
+
+def test_wct_facade_and_batch(ctx, weights):
+    from wct_tf_amd import WCT
+    targets = ['relu2_1', 'relu1_1']
+    model = WCT(checkpoints=None, relu_targets=targets, vgg_path=None, device='/gpu:0', weights=weights)
+    c = synthetic_image(1002, 48, 48)
+    s = synthetic_image(2002, 48, 48)
+    out = model.predict(c, s, alpha=0.8)
+    assert out.dtype == np.uint8 and out.shape == (48, 48, 3)
+    assert np.array_equal(out, ctx.stylize(c, s, targets, alpha=0.8))
+    with pytest.raises(Exception):
+        WCT(checkpoints=['/nonexistent'], relu_targets=targets, vgg_path='/nonexistent.npz')
+    with pytest.raises(NotImplementedError):
+        model.predict(c, s, swap5=True)
+    # batched device-resident entry point == per-pair calls, bit for bit
+    B = 3
+    cs = np.stack([synthetic_image(1000 + i, 48, 48) for i in range(B)])
+    ss = np.stack([synthetic_image(2000 + i, 48, 48) for i in range(B)])
+    sess = model.sess
+    dc, ds, do = sess.dev_alloc(cs.nbytes), sess.dev_alloc(ss.nbytes), sess.dev_alloc(cs.nbytes)
+    sess.h2d(dc, cs)
+    sess.h2d(ds, ss)
+    sess.stylize_batch_dev(dc, 48, 48, ds, 48, 48, B, targets, 0.8, do)
+    sess.sync()
+    outs = np.empty_like(cs)
+    sess.d2h(outs, do)
+    for i in range(B):
+        assert np.array_equal(outs[i], model.predict(cs[i], ss[i], alpha=0.8)), i
+    for p in (dc, ds, do):
+        sess.dev_free(p)

@@ -1,0 +1,244 @@
+"""Python handle on one wct_ctx (one GPU, one HIP stream) -- the session object
+that replaces the reference's tf.Session (wct.py:29-58).  Every method is a
+thin ctypes call into libwct_hip.so; no arithmetic of the path happens here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, f32, fptr, u8
+from .weights import ENCODER_CONVS, RELU_LEVEL, decoder_plan
+
+_LEVEL_C = {1: 64, 2: 128, 3: 256, 4: 512, 5: 512}
+
+
+def _levels(relu_targets):
+    out = []
+    for r in relu_targets:
+        if isinstance(r, str):
+            if r not in RELU_LEVEL:
+                raise ValueError('unknown relu target %r' % (r,))
+            out.append(RELU_LEVEL[r])
+        else:
+            out.append(int(r))
+    return out
+
+
+class Context(object):
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        check(self.lib.wct_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+        self.loaded_decoders = set()
+        self.encoder_loaded = False
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.wct_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.wct_sync(self.h))
+
+    # ---- weights ---------------------------------------------------------
+    def set_encoder(self, enc):
+        pre_w, pre_b = enc['preprocess']
+        pw = f32(np.asarray(pre_w).reshape(3, 3))
+        pb = f32(pre_b)
+        ws = [f32(enc[name][0]) for name, _, _ in ENCODER_CONVS]
+        bs = [f32(enc[name][1]) for name, _, _ in ENCODER_CONVS]
+        for (name, cin, cout), w in zip(ENCODER_CONVS, ws):
+            if w.shape != (3, 3, cin, cout):
+                raise ValueError('%s: expected HWIO %s, got %s' % (name, (3, 3, cin, cout), w.shape))
+        check(self.lib.wct_set_encoder(self.h, fptr(pw), fptr(pb), _lib.ptr_array(ws), _lib.ptr_array(bs), len(ws)))
+        self.encoder_loaded = True
+
+    def set_decoder(self, relu_target, layers):
+        level = _levels([relu_target])[0]
+        plan = [p for p in decoder_plan('relu%d_1' % level) if p[0] == 'C']
+        if len(layers) != len(plan):
+            raise ValueError('decoder relu%d_1 needs %d conv layers, got %d' % (level, len(plan), len(layers)))
+        ws = [f32(w) for w, _ in layers]
+        bs = [f32(b) for _, b in layers]
+        for (_, cin, cout, _), w in zip(plan, ws):
+            if w.shape != (3, 3, cin, cout):
+                raise ValueError('decoder relu%d_1: expected HWIO %s, got %s' % (level, (3, 3, cin, cout), w.shape))
+        check(self.lib.wct_set_decoder(self.h, level, _lib.ptr_array(ws), _lib.ptr_array(bs), len(ws)))
+        self.loaded_decoders.add(level)
+
+    def set_weights(self, weights):
+        self.set_encoder(weights['encoder'])
+        for relu, layers in weights['decoder'].items():
+            self.set_decoder(relu, layers)
+
+    # ---- op level ----------------------------------------------------------
+    def transform(self, content, style, alpha, mode, eps=-1.0, return_sweeps=False):
+        """content [Nc][C], style [Ns][C] float32 -> [Nc][C]"""
+        c = f32(content)
+        s = f32(style)
+        if c.ndim != 2 or s.ndim != 2 or c.shape[1] != s.shape[1]:
+            raise ValueError('expected [N][C] feature matrices with equal C')
+        out = np.empty_like(c)
+        sweeps = (C.c_int * 2)()
+        check(self.lib.wct_transform(self.h, fptr(c), c.shape[0], fptr(s), s.shape[0], c.shape[1],
+                                     float(alpha), int(mode), float(eps), fptr(out), sweeps))
+        return (out, list(sweeps)) if return_sweeps else out
+
+    def adain(self, content, style, alpha, epsilon=1e-5):
+        c = f32(content)
+        s = f32(style)
+        out = np.empty_like(c)
+        check(self.lib.wct_adain(self.h, fptr(c), c.shape[0], fptr(s), s.shape[0], c.shape[1],
+                                 float(alpha), float(epsilon), fptr(out)))
+        return out
+
+    def eigh(self, mats, return_sweeps=False):
+        a = f32(mats)
+        if a.ndim == 2:
+            a = a[None]
+        n, c, _ = a.shape
+        evals = np.empty((n, c), np.float32)
+        evecs = np.empty((n, c, c), np.float32)
+        sweeps = (C.c_int * n)()
+        check(self.lib.wct_eigh(self.h, fptr(a), c, n, fptr(evals), fptr(evecs), sweeps))
+        return (evals, evecs, list(sweeps)) if return_sweeps else (evals, evecs)
+
+    def conv3x3(self, x, w_hwio, bias, relu=True, upsample=False):
+        x = f32(x)
+        w = f32(w_hwio)
+        b = f32(bias)
+        h, wd, cin = x.shape
+        cout = w.shape[3]
+        s = 2 if upsample else 1
+        y = np.empty((h * s, wd * s, cout), np.float32)
+        check(self.lib.wct_conv3x3(self.h, fptr(x), h, wd, cin, fptr(w), fptr(b), cout, int(relu), int(upsample), fptr(y)))
+        return y
+
+    def maxpool(self, x):
+        x = f32(x)
+        h, w, c = x.shape
+        y = np.empty(((h + 1) // 2, (w + 1) // 2, c), np.float32)
+        check(self.lib.wct_maxpool(self.h, fptr(x), h, w, c, fptr(y)))
+        return y
+
+    def encode(self, img01, relu_target):
+        level = _levels([relu_target])[0]
+        x = f32(img01)
+        h, w, _ = x.shape
+        hh, ww = h, w
+        for _ in range(level - 1):
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+        feat = np.empty((hh, ww, _LEVEL_C[level]), np.float32)
+        check(self.lib.wct_encode(self.h, fptr(x), h, w, level, fptr(feat)))
+        return feat
+
+    def decode(self, feat, relu_target):
+        level = _levels([relu_target])[0]
+        f = f32(feat)
+        h, w, _ = f.shape
+        s = 1 << (level - 1)
+        img = np.empty((h * s, w * s, 3), np.float32)
+        check(self.lib.wct_decode(self.h, fptr(f), h, w, level, fptr(img)))
+        return img
+
+    def coral_stats(self, img_u8):
+        a = u8(img_u8)
+        sums = (C.c_double * 9)()
+        check(self.lib.wct_coral_stats(self.h, a.ctypes.data_as(_lib._U8), a.shape[0], a.shape[1], sums))
+        return np.array(list(sums), np.float64)
+
+    def coral_apply(self, src_u8, m, src_mean, src_std, tgt_mean, tgt_std, want_f64=True, want_u8=True):
+        a = u8(src_u8)
+        h, w, _ = a.shape
+        dd = lambda v: np.ascontiguousarray(v, np.float64).ctypes.data_as(_lib._D)
+        arrs = [np.ascontiguousarray(v, np.float64).reshape(-1) for v in (m, src_mean, src_std, tgt_mean, tgt_std)]
+        out8 = np.empty((h, w, 3), np.uint8) if want_u8 else None
+        out64 = np.empty((h, w, 3), np.float64) if want_f64 else None
+        check(self.lib.wct_coral_apply(
+            self.h, a.ctypes.data_as(_lib._U8), h, w, *[x.ctypes.data_as(_lib._D) for x in arrs],
+            out8.ctypes.data_as(_lib._U8) if want_u8 else None,
+            out64.ctypes.data_as(_lib._D) if want_f64 else None))
+        return out8, out64
+
+    # ---- the hot path ------------------------------------------------------
+    def output_size(self, hc, wc, relu_targets):
+        lv = _levels(relu_targets)
+        arr = (C.c_int * len(lv))(*lv)
+        ho, wo = C.c_int(), C.c_int()
+        check(self.lib.wct_output_size(hc, wc, arr, len(lv), C.byref(ho), C.byref(wo)))
+        return ho.value, wo.value
+
+    def stylize(self, content_u8, style_u8, relu_targets, alpha=1.0, adain=False, wct_mode='tf'):
+        c = u8(content_u8)
+        s = u8(style_u8)
+        lv = _levels(relu_targets)
+        arr = (C.c_int * len(lv))(*lv)
+        ho, wo = self.output_size(c.shape[0], c.shape[1], lv)
+        out = np.empty((ho, wo, 3), np.uint8)
+        flags = (_lib.FLAG_ADAIN if adain else 0) | (_lib.FLAG_MODE_NP if wct_mode == 'np' else 0)
+        check(self.lib.wct_stylize(self.h, c.ctypes.data_as(_lib._U8), c.shape[0], c.shape[1],
+                                   s.ctypes.data_as(_lib._U8), s.shape[0], s.shape[1], arr, len(lv),
+                                   float(alpha), flags, out.ctypes.data_as(_lib._U8)))
+        return out
+
+    # device-resident batch (what bench.py times)
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.wct_dev_alloc(self.h, int(nbytes), C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        check(self.lib.wct_dev_free(self.h, p))
+
+    def h2d(self, dst, arr):
+        a = np.ascontiguousarray(arr)
+        check(self.lib.wct_h2d(self.h, dst, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def d2h(self, arr, src):
+        assert arr.flags['C_CONTIGUOUS']
+        check(self.lib.wct_d2h(self.h, arr.ctypes.data_as(C.c_void_p), src, arr.nbytes))
+
+    def stylize_batch_dev(self, content_dev, hc, wc, style_dev, hs, ws, batch, relu_targets, alpha, out_dev,
+                          adain=False, wct_mode='tf'):
+        lv = _levels(relu_targets)
+        arr = (C.c_int * len(lv))(*lv)
+        flags = (_lib.FLAG_ADAIN if adain else 0) | (_lib.FLAG_MODE_NP if wct_mode == 'np' else 0)
+        check(self.lib.wct_stylize_batch_dev(self.h, content_dev, hc, wc, style_dev, hs, ws, batch, arr, len(lv),
+                                             float(alpha), flags, out_dev))
+
+    # ---- measurement -------------------------------------------------------
+    def prof_enable(self, on=True):
+        check(self.lib.wct_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        check(self.lib.wct_prof_reset(self.h))
+
+    def prof_read(self):
+        n = len(_lib.PROF_CLASSES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_longlong * n)()
+        fl = (C.c_double * n)()
+        by = (C.c_double * n)()
+        check(self.lib.wct_prof_read(self.h, ms, cnt, fl, by))
+        return {name: {'ms': ms[i], 'launches': cnt[i], 'flops': fl[i], 'bytes': by[i]}
+                for i, name in enumerate(_lib.PROF_CLASSES)}
+
+
+_default = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (the reference has one session per WCT object;
+    the op-level functions in ops.py share this one)."""
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]

@@ -1,0 +1,711 @@
+// C ABI of libwct_hip.so (see include/wct_hip.h): context, weight upload, and the
+// host-side orchestration of one WCT.predict (wct.py:70-106) as a chain of HIP
+// kernel launches on a single stream.  Nothing here touches the CPU oracle.
+#include "common.h"
+#include "../../include/wct_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void wct_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* wct_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct ConvLayer {
+  half_t* w = nullptr;   // [cout][9][cin]
+  float* b = nullptr;
+  int cin = 0, cout = 0;
+};
+
+struct PlanStep { char kind; int cin, cout, relu; };   // 'C' or 'U'
+
+struct Decoder {
+  bool loaded = false;
+  std::vector<PlanStep> plan;
+  std::vector<ConvLayer> convs;    // every conv but the last
+  float* last_w = nullptr;         // [576][3] fp32
+  float* last_b = nullptr;
+};
+
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+
+struct wct_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool enc_loaded = false;
+  float* first_w = nullptr;        // folded conv1_1 [27][64]
+  float* first_b = nullptr;
+  ConvLayer enc[12];               // conv1_2 .. conv5_1
+  Decoder dec[6];
+  DevBuf act[2], feat_c, feat_s[6], img_c, img_s, img_t[2], wct_out, wct_ws, stage[4];
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+  double prof_ms[WCT_PROF_CLASSES] = {0};
+  long long prof_n[WCT_PROF_CLASSES] = {0};
+  double prof_flops[WCT_PROF_CLASSES] = {0};
+  double prof_bytes[WCT_PROF_CLASSES] = {0};
+};
+
+static const int LEVEL_C[6] = {0, 64, 128, 256, 512, 512};
+static const int ENC_CIN[12] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512};
+static const int ENC_COUT[12] = {64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512};
+
+static int ensure(wct_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.cap >= bytes) return WCT_OK;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (b.p) HIP_TRY(hipFree(b.p));
+  b.p = nullptr; b.cap = 0;
+  size_t want = bytes + bytes / 8 + 4096;
+  HIP_TRY(hipMalloc(&b.p, want));
+  b.cap = want;
+  return WCT_OK;
+}
+
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+struct ProfScope {
+  wct_ctx* c; ProfRec r; bool on;
+  ProfScope(wct_ctx* ctx, int cls, double flops, double bytes) : c(ctx), on(ctx->prof) {
+    if (!on) return;
+    if (c->free_events.empty()) {
+      hipEventCreate(&r.a); hipEventCreate(&r.b);
+    } else {
+      r.a = c->free_events.back().first; r.b = c->free_events.back().second;
+      c->free_events.pop_back();
+    }
+    r.cls = cls; r.flops = flops; r.bytes = bytes;
+    hipEventRecord(r.a, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(r.b, c->stream);
+    c->recs.push_back(r);
+  }
+};
+
+extern "C" int wct_device_count(int* n) {
+  ARG_CHECK(n != nullptr);
+  HIP_TRY(hipGetDeviceCount(n));
+  return WCT_OK;
+}
+
+extern "C" int wct_create(int device, wct_ctx** out) {
+  ARG_CHECK(out != nullptr);
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (n <= 0 || device < 0 || device >= n) {
+    wct_set_error("no such HIP device %d (count %d)", device, n);
+    return WCT_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(device));
+  wct_ctx* c = new wct_ctx();
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    wct_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete c;
+    return WCT_ERR_HIP;
+  }
+  *out = c;
+  return WCT_OK;
+}
+
+static void free_layer(ConvLayer& l) {
+  if (l.w) hipFree(l.w);
+  if (l.b) hipFree(l.b);
+  l = ConvLayer();
+}
+static void free_decoder(Decoder& d) {
+  for (auto& l : d.convs) free_layer(l);
+  if (d.last_w) hipFree(d.last_w);
+  if (d.last_b) hipFree(d.last_b);
+  d = Decoder();
+}
+
+extern "C" void wct_destroy(wct_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  if (c->first_w) hipFree(c->first_w);
+  if (c->first_b) hipFree(c->first_b);
+  for (auto& l : c->enc) free_layer(l);
+  for (auto& d : c->dec) free_decoder(d);
+  DevBuf* bufs[] = {&c->act[0], &c->act[1], &c->feat_c, &c->img_c, &c->img_s, &c->img_t[0], &c->img_t[1],
+                    &c->wct_out, &c->wct_ws, &c->stage[0], &c->stage[1], &c->stage[2], &c->stage[3]};
+  for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  for (auto& b : c->feat_s) if (b.p) hipFree(b.p);
+  for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto& e : c->free_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int wct_sync(wct_ctx* c) {
+  ARG_CHECK(c != nullptr);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return WCT_OK;
+}
+
+extern "C" int wct_dev_alloc(wct_ctx* c, size_t bytes, void** out) {
+  ARG_CHECK(c && out && bytes > 0);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc(out, bytes));
+  return WCT_OK;
+}
+extern "C" int wct_dev_free(wct_ctx* c, void* p) {
+  ARG_CHECK(c != nullptr);
+  if (p) HIP_TRY(hipFree(p));
+  return WCT_OK;
+}
+extern "C" int wct_h2d(wct_ctx* c, void* dst, const void* src, size_t bytes) {
+  ARG_CHECK(c && dst && src);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return WCT_OK;
+}
+extern "C" int wct_d2h(wct_ctx* c, void* dst, const void* src, size_t bytes) {
+  ARG_CHECK(c && dst && src);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------
+extern "C" int wct_prof_enable(wct_ctx* c, int on) {
+  ARG_CHECK(c != nullptr);
+  c->prof = on != 0;
+  return WCT_OK;
+}
+static int prof_drain(wct_ctx* c) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (auto& r : c->recs) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    c->prof_ms[r.cls] += ms;
+    c->prof_n[r.cls] += 1;
+    c->prof_flops[r.cls] += r.flops;
+    c->prof_bytes[r.cls] += r.bytes;
+    c->free_events.push_back({r.a, r.b});
+  }
+  c->recs.clear();
+  return WCT_OK;
+}
+extern "C" int wct_prof_reset(wct_ctx* c) {
+  ARG_CHECK(c != nullptr);
+  TRY(prof_drain(c));
+  for (int i = 0; i < WCT_PROF_CLASSES; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_flops[i] = 0; c->prof_bytes[i] = 0; }
+  return WCT_OK;
+}
+extern "C" int wct_prof_read(wct_ctx* c, double ms[WCT_PROF_CLASSES], long long launches[WCT_PROF_CLASSES],
+                             double flops[WCT_PROF_CLASSES], double bytes[WCT_PROF_CLASSES]) {
+  ARG_CHECK(c != nullptr);
+  TRY(prof_drain(c));
+  for (int i = 0; i < WCT_PROF_CLASSES; ++i) {
+    if (ms) ms[i] = c->prof_ms[i];
+    if (launches) launches[i] = c->prof_n[i];
+    if (flops) flops[i] = c->prof_flops[i];
+    if (bytes) bytes[i] = c->prof_bytes[i];
+  }
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------
+static int upload(wct_ctx* c, const void* host, size_t bytes, void** dev) {
+  HIP_TRY(hipMalloc(dev, bytes));
+  HIP_TRY(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return WCT_OK;
+}
+
+// HWIO fp32 -> [cout][tap][cin] fp16
+static int pack_conv(wct_ctx* c, const float* w_hwio, const float* b, int cin, int cout, ConvLayer* out) {
+  free_layer(*out);
+  std::vector<half_t> packed((size_t)cout * 9 * cin);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int co = 0; co < cout; ++co)
+        packed[((size_t)co * 9 + tap) * cin + ci] = (half_t)w_hwio[((size_t)tap * cin + ci) * cout + co];
+  TRY(upload(c, packed.data(), packed.size() * sizeof(half_t), (void**)&out->w));
+  TRY(upload(c, b, (size_t)cout * sizeof(float), (void**)&out->b));
+  out->cin = cin; out->cout = cout;
+  return WCT_OK;
+}
+
+extern "C" int wct_set_encoder(wct_ctx* c, const float* pre_w, const float* pre_b,
+                               const float* const* w, const float* const* b, int n_layers) {
+  ARG_CHECK(c && pre_w && pre_b && w && b && n_layers == 13);
+  HIP_TRY(hipSetDevice(c->device));
+  // fold the pointwise 'preprocess' conv (vgg_normalised.py:25-26) into conv1_1: a pointwise
+  // op commutes with the reflect pad, so  conv1_1(pad(P x + pb)) = conv1_1'(pad(x)) exactly.
+  std::vector<float> fw(27 * 64), fb(64);
+  const float* w1 = w[0];   // [3][3][3][64]
+  for (int co = 0; co < 64; ++co) {
+    double acc = b[0][co];
+    for (int tap = 0; tap < 9; ++tap)
+      for (int cp = 0; cp < 3; ++cp) acc += (double)pre_b[cp] * w1[(tap * 3 + cp) * 64 + co];
+    fb[co] = (float)acc;
+  }
+  for (int tap = 0; tap < 9; ++tap)
+    for (int ci = 0; ci < 3; ++ci)
+      for (int co = 0; co < 64; ++co) {
+        double acc = 0;
+        for (int cp = 0; cp < 3; ++cp) acc += (double)pre_w[ci * 3 + cp] * w1[(tap * 3 + cp) * 64 + co];
+        fw[(tap * 3 + ci) * 64 + co] = (float)acc;
+      }
+  if (c->first_w) { hipFree(c->first_w); c->first_w = nullptr; }
+  if (c->first_b) { hipFree(c->first_b); c->first_b = nullptr; }
+  TRY(upload(c, fw.data(), fw.size() * sizeof(float), (void**)&c->first_w));
+  TRY(upload(c, fb.data(), fb.size() * sizeof(float), (void**)&c->first_b));
+  for (int i = 0; i < 12; ++i) TRY(pack_conv(c, w[i + 1], b[i + 1], ENC_CIN[i], ENC_COUT[i], &c->enc[i]));
+  c->enc_loaded = true;
+  return WCT_OK;
+}
+
+static std::vector<PlanStep> decoder_plan(int level) {
+  // model.py:255-277 walked from `level` down to 1, then the 3-filter output conv (model.py:298)
+  static const int arch5[] = {512, -1, 512, 512, 512, 0};
+  static const int arch4[] = {256, -1, 256, 256, 256, 0};
+  static const int arch3[] = {128, -1, 128, 0};
+  static const int arch2[] = {64, -1, 0};
+  static const int arch1[] = {64, 0};
+  static const int* archs[6] = {nullptr, arch1, arch2, arch3, arch4, arch5};
+  std::vector<PlanStep> plan;
+  int cin = LEVEL_C[level];
+  for (int d = level; d >= 1; --d)
+    for (const int* a = archs[d]; *a != 0; ++a) {
+      if (*a < 0) plan.push_back({'U', cin, cin, 0});
+      else { plan.push_back({'C', cin, *a, 1}); cin = *a; }
+    }
+  plan.push_back({'C', cin, 3, 0});
+  return plan;
+}
+
+extern "C" int wct_set_decoder(wct_ctx* c, int level, const float* const* w, const float* const* b, int n_layers) {
+  ARG_CHECK(c && w && b && level >= 1 && level <= 5);
+  HIP_TRY(hipSetDevice(c->device));
+  Decoder& d = c->dec[level];
+  free_decoder(d);
+  d.plan = decoder_plan(level);
+  int nconv = 0;
+  for (auto& s : d.plan) nconv += s.kind == 'C';
+  if (n_layers != nconv) {
+    wct_set_error("decoder relu%d_1 needs %d conv layers, got %d", level, nconv, n_layers);
+    return WCT_ERR_ARG;
+  }
+  int i = 0;
+  for (auto& s : d.plan) {
+    if (s.kind != 'C') continue;
+    if (s.cout == 3) {
+      // [3][3][64][3] HWIO is already [(tap*64+cin)][3]
+      TRY(upload(c, w[i], (size_t)576 * 3 * sizeof(float), (void**)&d.last_w));
+      TRY(upload(c, b[i], 3 * sizeof(float), (void**)&d.last_b));
+    } else {
+      d.convs.emplace_back();
+      TRY(pack_conv(c, w[i], b[i], s.cin, s.cout, &d.convs.back()));
+    }
+    ++i;
+  }
+  d.loaded = true;
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// encoder / decoder drivers (device pointers, batch B)
+// ---------------------------------------------------------------------------
+static void level_dims(int H, int W, int level, int* h, int* w) {
+  for (int l = 1; l < level; ++l) { H = (H + 1) / 2; W = (W + 1) / 2; }   // 'same' pooling = ceil
+  *h = H; *w = W;
+}
+
+static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16, float* y32,
+                    int B, int H, int W, int upsample, int relu) {
+  ConvArgs a;
+  a.x = x; a.w = l.w; a.bias = l.b; a.y16 = y16; a.y32 = y32;
+  a.B = B; a.H = H; a.W = W; a.Cin = l.cin; a.Cout = l.cout; a.upsample = upsample; a.relu = relu;
+  const double px = (double)B * H * W;
+  const double in_px = upsample ? px / 4 : px;
+  ProfScope ps(c, 0, 2.0 * px * 9 * l.cin * l.cout,
+               in_px * l.cin * 2 + px * l.cout * ((y16 ? 2 : 0) + (y32 ? 4 : 0)) + 9.0 * l.cin * l.cout * 2);
+  return launch_conv3x3(a, c->stream);
+}
+
+// img: [B][H][W][3] fp32 device.  taps32[l] (l=1..5): fp32 feature output for relu<l>_1 or null.
+static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int clamp01, int deepest,
+                       float* const taps32[6]) {
+  if (!c->enc_loaded) { wct_set_error("encoder weights not set (wct_set_encoder)"); return WCT_ERR_STATE; }
+  ARG_CHECK(deepest >= 1 && deepest <= 5 && H >= 2 && W >= 2);
+  const size_t act_bytes = (size_t)B * H * W * 64 * sizeof(half_t);
+  TRY(ensure(c, c->act[0], act_bytes));
+  TRY(ensure(c, c->act[1], act_bytes));
+  half_t* cur = (half_t*)c->act[0].p;
+  half_t* nxt = (half_t*)c->act[1].p;
+  {
+    ConvFirstArgs a;
+    a.x = img; a.w = c->first_w; a.bias = c->first_b;
+    a.y16 = deepest > 1 ? cur : nullptr; a.y32 = taps32[1];
+    a.B = B; a.H = H; a.W = W; a.clamp01 = clamp01;
+    const double px = (double)B * H * W;
+    ProfScope ps(c, 1, 2.0 * px * 27 * 64, px * (12 + 64 * ((a.y16 ? 2 : 0) + (a.y32 ? 4 : 0))));
+    TRY(launch_conv_first(a, c->stream));
+  }
+  if (deepest == 1) return WCT_OK;
+  // (layer index into enc[], level whose relu*_1 it produces or 0, pool before it?)
+  static const int seq_tap[12] = {0, 2, 0, 3, 0, 0, 0, 4, 0, 0, 0, 5};
+  static const int pool_before[12] = {0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+  int h = H, w = W;
+  for (int i = 0; i < 12; ++i) {
+    const ConvLayer& l = c->enc[i];
+    if (pool_before[i]) {
+      ProfScope ps(c, 3, 0, (double)B * h * w * l.cin * 2 * 1.25);
+      TRY(launch_maxpool2x2(cur, nxt, B, h, w, l.cin, c->stream));
+      h = (h + 1) / 2; w = (w + 1) / 2;
+      half_t* t = cur; cur = nxt; nxt = t;
+    }
+    const int tap = seq_tap[i];
+    const bool last = tap == deepest;
+    TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1));
+    half_t* t = cur; cur = nxt; nxt = t;
+    if (last) break;
+  }
+  return WCT_OK;
+}
+
+// feat16: [B][h][w][C] fp16 device (may alias neither act buffer). img_out: [B][h*2^(l-1)][..][3] fp32
+static int run_decoder(wct_ctx* c, int level, const half_t* feat16, int B, int h, int w, float* img_out) {
+  Decoder& d = c->dec[level];
+  if (!d.loaded) { wct_set_error("decoder weights for relu%d_1 not set (wct_set_decoder)", level); return WCT_ERR_STATE; }
+  const int scale = 1 << (level - 1);
+  const size_t act_bytes = (size_t)B * h * scale * w * scale * 64 * sizeof(half_t);
+  const size_t deep_bytes = (size_t)B * h * w * LEVEL_C[level] * sizeof(half_t) * 4;   // after the first upsample, <= 4x
+  TRY(ensure(c, c->act[0], act_bytes > deep_bytes ? act_bytes : deep_bytes));
+  TRY(ensure(c, c->act[1], act_bytes > deep_bytes ? act_bytes : deep_bytes));
+  const half_t* cur = feat16;
+  half_t* bufs[2] = {(half_t*)c->act[0].p, (half_t*)c->act[1].p};
+  int which = 0, ci = 0, up = 0;
+  for (auto& s : d.plan) {
+    if (s.kind == 'U') { up = 1; h *= 2; w *= 2; continue; }
+    if (s.cout == 3) {
+      ARG_CHECK(up == 0);
+      ConvLastArgs a;
+      a.x = cur; a.w = d.last_w; a.bias = d.last_b; a.y = img_out; a.B = B; a.H = h; a.W = w;
+      const double px = (double)B * h * w;
+      ProfScope ps(c, 2, 2.0 * px * 576 * 3, px * (128 + 12));
+      TRY(launch_conv_last(a, c->stream));
+    } else {
+      half_t* out = bufs[which];
+      TRY(run_conv(c, d.convs[ci++], cur, out, nullptr, B, h, w, up, 1));
+      cur = out; which ^= 1; up = 0;
+    }
+  }
+  return WCT_OK;
+}
+
+static int run_transform(wct_ctx* c, const float* fc, int Nc, const float* fs, int Ns, int C, int P,
+                         float alpha, unsigned flags, float eps, half_t* out16, float* out32, int* sweeps_dev) {
+  const size_t ws = wct_workspace_bytes(C, Nc, Ns, P);
+  TRY(ensure(c, c->wct_ws, ws));
+  if (flags & WCT_FLAG_ADAIN) {
+    ProfScope ps(c, 7, 0, (double)P * (2.0 * Nc + 2.0 * Ns) * C * 4 + (double)P * Nc * C * 6);
+    return launch_adain(fc, Nc, fs, Ns, C, P, alpha, 1e-5f, out16, out32, c->wct_ws.p, c->wct_ws.cap, c->stream);
+  }
+  const int mode = (flags & WCT_FLAG_MODE_NP) ? WCT_MODE_NP : WCT_MODE_TF;
+  {
+    ProfScope ps(c, 4, (double)P * 2.0 * C * C * ((double)Nc + Ns), (double)P * 2.0 * ((double)Nc + Ns) * C * 4);
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream));
+  }
+  {
+    ProfScope ps(c, 5, 0, 0);
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_EIG, c->stream));
+  }
+  ProfScope ps(c, 6, (double)P * (2.0 * C * C * Nc + 6.0 * C * C * C), (double)P * Nc * C * (4 + (out16 ? 2 : 0) + (out32 ? 4 : 0)));
+  return launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_APPLY, c->stream);
+}
+
+// ---------------------------------------------------------------------------
+// op-level host entry points
+// ---------------------------------------------------------------------------
+static int stage_in(wct_ctx* c, int slot, const void* host, size_t bytes, void** dev) {
+  TRY(ensure(c, c->stage[slot], bytes));
+  HIP_TRY(hipMemcpyAsync(c->stage[slot].p, host, bytes, hipMemcpyHostToDevice, c->stream));
+  *dev = c->stage[slot].p;
+  return WCT_OK;
+}
+static int fetch(wct_ctx* c, void* host, const void* dev, size_t bytes) {
+  HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return WCT_OK;
+}
+
+extern "C" int wct_transform(wct_ctx* c, const float* content, int Nc, const float* style, int Ns, int C,
+                             float alpha, int mode, float eps, float* out, int* sweeps_out) {
+  ARG_CHECK(c && content && style && out && (mode == WCT_NP || mode == WCT_TF));
+  HIP_TRY(hipSetDevice(c->device));
+  void *dc, *ds;
+  TRY(stage_in(c, 0, content, (size_t)Nc * C * 4, &dc));
+  TRY(stage_in(c, 1, style, (size_t)Ns * C * 4, &ds));
+  TRY(ensure(c, c->stage[2], (size_t)Nc * C * 4));
+  TRY(ensure(c, c->stage[3], 256));
+  TRY(run_transform(c, (float*)dc, Nc, (float*)ds, Ns, C, 1, alpha, mode == WCT_NP ? WCT_FLAG_MODE_NP : 0, eps,
+                    nullptr, (float*)c->stage[2].p, (int*)c->stage[3].p));
+  TRY(fetch(c, out, c->stage[2].p, (size_t)Nc * C * 4));
+  if (sweeps_out) TRY(fetch(c, sweeps_out, c->stage[3].p, 2 * sizeof(int)));
+  return WCT_OK;
+}
+
+extern "C" int wct_adain(wct_ctx* c, const float* content, int Nc, const float* style, int Ns, int C,
+                         float alpha, float epsilon, float* out) {
+  ARG_CHECK(c && content && style && out);
+  HIP_TRY(hipSetDevice(c->device));
+  void *dc, *ds;
+  TRY(stage_in(c, 0, content, (size_t)Nc * C * 4, &dc));
+  TRY(stage_in(c, 1, style, (size_t)Ns * C * 4, &ds));
+  TRY(ensure(c, c->stage[2], (size_t)Nc * C * 4));
+  TRY(ensure(c, c->wct_ws, wct_workspace_bytes(C, Nc, Ns, 1)));
+  TRY(launch_adain((float*)dc, Nc, (float*)ds, Ns, C, 1, alpha, epsilon, nullptr, (float*)c->stage[2].p,
+                   c->wct_ws.p, c->wct_ws.cap, c->stream));
+  return fetch(c, out, c->stage[2].p, (size_t)Nc * C * 4);
+}
+
+__global__ void extract_diag_kernel(const float* A, float* d, int C) {
+  const int m = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < C) d[m * C + k] = A[(size_t)m * C * C + (size_t)k * C + k];
+}
+
+extern "C" int wct_eigh(wct_ctx* c, const float* A, int C, int nmat, float* evals, float* evecs, int* sweeps_out) {
+  ARG_CHECK(c && A && evals && evecs && nmat >= 1 && nmat <= 64);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t mb = (size_t)nmat * C * C * 4;
+  void* dA;
+  TRY(stage_in(c, 0, A, mb, &dA));
+  TRY(ensure(c, c->stage[1], mb));
+  TRY(ensure(c, c->stage[2], (size_t)nmat * C * 4 + 1024));
+  TRY(ensure(c, c->wct_ws, jacobi_workspace_bytes(C, nmat)));
+  int* sw = (int*)((char*)c->stage[2].p + (size_t)nmat * C * 4);
+  {
+    ProfScope ps(c, 5, 0, 0);
+    TRY(launch_jacobi_eigh((float*)dA, (float*)c->stage[1].p, C, nmat, c->wct_ws.p, c->wct_ws.cap, sw, c->stream));
+  }
+  hipLaunchKernelGGL(extract_diag_kernel, dim3(cdiv(C, 256), nmat), dim3(256), 0, c->stream, (float*)dA, (float*)c->stage[2].p, C);
+  TRY(fetch(c, evals, c->stage[2].p, (size_t)nmat * C * 4));
+  TRY(fetch(c, evecs, c->stage[1].p, mb));
+  if (sweeps_out) TRY(fetch(c, sweeps_out, sw, nmat * sizeof(int)));
+  return WCT_OK;
+}
+
+extern "C" int wct_conv3x3(wct_ctx* c, const float* x, int H, int W, int Cin, const float* w_hwio, const float* bias,
+                           int Cout, int relu, int upsample, float* y) {
+  ARG_CHECK(c && x && w_hwio && bias && y);
+  HIP_TRY(hipSetDevice(c->device));
+  const int Ho = upsample ? 2 * H : H, Wo = upsample ? 2 * W : W;
+  ConvLayer l;
+  TRY(pack_conv(c, w_hwio, bias, Cin, Cout, &l));
+  void* dx;
+  int rc = stage_in(c, 0, x, (size_t)H * W * Cin * 4, &dx);
+  if (!rc) rc = ensure(c, c->stage[1], (size_t)H * W * Cin * 2);
+  if (!rc) rc = ensure(c, c->stage[2], (size_t)Ho * Wo * Cout * 4);
+  if (!rc) rc = launch_f32_to_f16((float*)dx, (half_t*)c->stage[1].p, (size_t)H * W * Cin, c->stream);
+  if (!rc) rc = run_conv(c, l, (half_t*)c->stage[1].p, nullptr, (float*)c->stage[2].p, 1, Ho, Wo, upsample, relu);
+  if (!rc) rc = fetch(c, y, c->stage[2].p, (size_t)Ho * Wo * Cout * 4);
+  hipStreamSynchronize(c->stream);
+  free_layer(l);
+  return rc;
+}
+
+extern "C" int wct_maxpool(wct_ctx* c, const float* x, int H, int W, int C, float* y) {
+  ARG_CHECK(c && x && y && C % 8 == 0);
+  HIP_TRY(hipSetDevice(c->device));
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  void* dx;
+  TRY(stage_in(c, 0, x, (size_t)H * W * C * 4, &dx));
+  TRY(ensure(c, c->stage[1], (size_t)H * W * C * 2));
+  TRY(ensure(c, c->stage[2], (size_t)Ho * Wo * C * 2));
+  TRY(ensure(c, c->stage[3], (size_t)Ho * Wo * C * 4));
+  TRY(launch_f32_to_f16((float*)dx, (half_t*)c->stage[1].p, (size_t)H * W * C, c->stream));
+  TRY(launch_maxpool2x2((half_t*)c->stage[1].p, (half_t*)c->stage[2].p, 1, H, W, C, c->stream));
+  TRY(launch_f16_to_f32((half_t*)c->stage[2].p, (float*)c->stage[3].p, (size_t)Ho * Wo * C, c->stream));
+  return fetch(c, y, c->stage[3].p, (size_t)Ho * Wo * C * 4);
+}
+
+extern "C" int wct_encode(wct_ctx* c, const float* img01, int H, int W, int level, float* feat) {
+  ARG_CHECK(c && img01 && feat && level >= 1 && level <= 5);
+  HIP_TRY(hipSetDevice(c->device));
+  int h, w;
+  level_dims(H, W, level, &h, &w);
+  void* dimg;
+  TRY(stage_in(c, 0, img01, (size_t)H * W * 3 * 4, &dimg));
+  const size_t fb = (size_t)h * w * LEVEL_C[level] * 4;
+  TRY(ensure(c, c->feat_c, fb));
+  float* taps[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  taps[level] = (float*)c->feat_c.p;
+  TRY(run_encoder(c, (float*)dimg, 1, H, W, 0, level, taps));
+  return fetch(c, feat, c->feat_c.p, fb);
+}
+
+extern "C" int wct_decode(wct_ctx* c, const float* feat, int h, int w, int level, float* img) {
+  ARG_CHECK(c && feat && img && level >= 1 && level <= 5);
+  HIP_TRY(hipSetDevice(c->device));
+  const int C = LEVEL_C[level], scale = 1 << (level - 1);
+  void* df;
+  TRY(stage_in(c, 0, feat, (size_t)h * w * C * 4, &df));
+  TRY(ensure(c, c->wct_out, (size_t)h * w * C * 2));
+  TRY(launch_f32_to_f16((float*)df, (half_t*)c->wct_out.p, (size_t)h * w * C, c->stream));
+  const size_t ib = (size_t)h * scale * w * scale * 3 * 4;
+  TRY(ensure(c, c->img_t[0], ib));
+  TRY(run_decoder(c, level, (half_t*)c->wct_out.p, 1, h, w, (float*)c->img_t[0].p));
+  return fetch(c, img, c->img_t[0].p, ib);
+}
+
+extern "C" int wct_coral_stats(wct_ctx* c, const uint8_t* img, int H, int W, double sums[9]) {
+  ARG_CHECK(c && img && sums && H > 0 && W > 0);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t npix = (size_t)H * W;
+  void* dimg;
+  TRY(stage_in(c, 0, img, npix * 3, &dimg));
+  int nblocks = (int)((npix + 255) / 256);
+  if (nblocks > 1024) nblocks = 1024;
+  TRY(ensure(c, c->stage[1], (size_t)(nblocks + 1) * 9 * sizeof(unsigned long long)));
+  unsigned long long* partial = (unsigned long long*)c->stage[1].p;
+  unsigned long long* out9 = partial + (size_t)nblocks * 9;
+  TRY(launch_coral_stats((uint8_t*)dimg, npix, partial, nblocks, out9, c->stream));
+  unsigned long long host9[9];
+  TRY(fetch(c, host9, out9, sizeof(host9)));
+  for (int k = 0; k < 9; ++k) sums[k] = (double)host9[k];     // exact: < 2^53
+  return WCT_OK;
+}
+
+extern "C" int wct_coral_apply(wct_ctx* c, const uint8_t* src, int H, int W, const double M[9],
+                               const double src_mean[3], const double src_std[3], const double tgt_mean[3],
+                               const double tgt_std[3], uint8_t* out_u8, double* out_f64) {
+  ARG_CHECK(c && src && M && src_mean && src_std && tgt_mean && tgt_std && (out_u8 || out_f64) && H > 0 && W > 0);
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t npix = (size_t)H * W;
+  CoralApplyArgs a;
+  for (int i = 0; i < 9; ++i) a.M[i] = M[i];
+  for (int i = 0; i < 3; ++i) { a.src_mean[i] = src_mean[i]; a.src_std[i] = src_std[i]; a.tgt_mean[i] = tgt_mean[i]; a.tgt_std[i] = tgt_std[i]; }
+  void* dsrc;
+  TRY(stage_in(c, 0, src, npix * 3, &dsrc));
+  if (out_u8) TRY(ensure(c, c->stage[1], npix * 3));
+  if (out_f64) TRY(ensure(c, c->stage[2], npix * 3 * sizeof(double)));
+  TRY(launch_coral_apply((uint8_t*)dsrc, npix, a, out_u8 ? (uint8_t*)c->stage[1].p : nullptr,
+                         out_f64 ? (double*)c->stage[2].p : nullptr, c->stream));
+  if (out_u8) TRY(fetch(c, out_u8, c->stage[1].p, npix * 3));
+  if (out_f64) TRY(fetch(c, out_f64, c->stage[2].p, npix * 3 * sizeof(double)));
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the hot path
+// ---------------------------------------------------------------------------
+extern "C" int wct_output_size(int Hc, int Wc, const int* levels, int n_levels, int* Ho, int* Wo) {
+  ARG_CHECK(levels && Ho && Wo && n_levels >= 1 && Hc >= 2 && Wc >= 2);
+  int H = Hc, W = Wc;
+  for (int i = 0; i < n_levels; ++i) {
+    ARG_CHECK(levels[i] >= 1 && levels[i] <= 5);
+    int h, w;
+    level_dims(H, W, levels[i], &h, &w);
+    H = h << (levels[i] - 1); W = w << (levels[i] - 1);     // ceil pooling then x2 upsampling
+  }
+  *Ho = H; *Wo = W;
+  return WCT_OK;
+}
+
+extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc, int Wc, const uint8_t* style,
+                                     int Hs, int Ws, int B, const int* levels, int n_levels, float alpha,
+                                     unsigned flags, uint8_t* out) {
+  ARG_CHECK(c && content && style && out && levels && n_levels >= 1 && n_levels <= 16 && B >= 1 && B <= 32);
+  HIP_TRY(hipSetDevice(c->device));
+  int deepest = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    ARG_CHECK(levels[i] >= 1 && levels[i] <= 5);
+    if (levels[i] > deepest) deepest = levels[i];
+    if (!c->dec[levels[i]].loaded) { wct_set_error("decoder weights for relu%d_1 not set", levels[i]); return WCT_ERR_STATE; }
+  }
+  int Ho, Wo;
+  TRY(wct_output_size(Hc, Wc, levels, n_levels, &Ho, &Wo));
+
+  // images to fp32 in [0,1] (wct.py:60-64)
+  const size_t nc = (size_t)B * Hc * Wc * 3, ns = (size_t)B * Hs * Ws * 3;
+  TRY(ensure(c, c->img_c, nc * 4));
+  TRY(ensure(c, c->img_s, ns * 4));
+  {
+    ProfScope ps(c, 7, 0, (double)(nc + ns) * 5);
+    TRY(launch_u8_to_f32(content, (float*)c->img_c.p, nc, c->stream));
+    TRY(launch_u8_to_f32(style, (float*)c->img_s.p, ns, c->stream));
+  }
+  // ONE style pass with a tap per requested level (model.py:69-75)
+  float* taps[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < n_levels; ++i) {
+    const int l = levels[i];
+    int h, w;
+    level_dims(Hs, Ws, l, &h, &w);
+    TRY(ensure(c, c->feat_s[l], (size_t)B * h * w * LEVEL_C[l] * 4));
+    taps[l] = (float*)c->feat_s[l].p;
+  }
+  TRY(run_encoder(c, (float*)c->img_s.p, B, Hs, Ws, 0, deepest, taps));
+
+  const float* cur = (float*)c->img_c.p;
+  int H = Hc, W = Wc;
+  for (int i = 0; i < n_levels; ++i) {
+    const int l = levels[i], C = LEVEL_C[l];
+    int h, w, hs, ws;
+    level_dims(H, W, l, &h, &w);
+    level_dims(Hs, Ws, l, &hs, &ws);
+    TRY(ensure(c, c->feat_c, (size_t)B * h * w * C * 4));
+    float* ctaps[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ctaps[l] = (float*)c->feat_c.p;
+    // level i>0 encodes clip(previous decoded, 0, 1) (model.py:86): the clamp is in the conv1_1 loader
+    TRY(run_encoder(c, cur, B, H, W, i > 0, l, ctaps));
+    TRY(ensure(c, c->wct_out, (size_t)B * h * w * C * 2));
+    TRY(run_transform(c, (float*)c->feat_c.p, h * w, (float*)c->feat_s[l].p, hs * ws, C, B, alpha, flags, -1.f,
+                      (half_t*)c->wct_out.p, nullptr, nullptr));
+    const int scale = 1 << (l - 1);
+    const int H2 = h * scale, W2 = w * scale;
+    DevBuf& dst = c->img_t[i & 1];
+    TRY(ensure(c, dst, (size_t)B * H2 * W2 * 3 * 4));
+    TRY(run_decoder(c, l, (half_t*)c->wct_out.p, B, h, w, (float*)dst.p));
+    cur = (float*)dst.p; H = H2; W = W2;
+  }
+  {
+    ProfScope ps(c, 7, 0, (double)B * H * W * 3 * 5);
+    TRY(launch_f32_to_u8(cur, out, (size_t)B * H * W * 3, c->stream));     // wct.py:66-68
+  }
+  return WCT_OK;
+}
+
+extern "C" int wct_stylize(wct_ctx* c, const uint8_t* content, int Hc, int Wc, const uint8_t* style, int Hs, int Ws,
+                           const int* levels, int n_levels, float alpha, unsigned flags, uint8_t* out) {
+  ARG_CHECK(c && content && style && out);
+  HIP_TRY(hipSetDevice(c->device));
+  int Ho, Wo;
+  TRY(wct_output_size(Hc, Wc, levels, n_levels, &Ho, &Wo));
+  void *dc, *ds;
+  TRY(stage_in(c, 0, content, (size_t)Hc * Wc * 3, &dc));
+  TRY(stage_in(c, 1, style, (size_t)Hs * Ws * 3, &ds));
+  TRY(ensure(c, c->stage[2], (size_t)Ho * Wo * 3));
+  TRY(wct_stylize_batch_dev(c, (uint8_t*)dc, Hc, Wc, (uint8_t*)ds, Hs, Ws, 1, levels, n_levels, alpha, flags,
+                            (uint8_t*)c->stage[2].p));
+  return fetch(c, out, c->stage[2].p, (size_t)Ho * Wo * 3);
+}

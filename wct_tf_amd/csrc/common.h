@@ -1,0 +1,108 @@
+// Shared declarations for libwct_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WCT_OK 0
+#define WCT_ERR_HIP -1
+#define WCT_ERR_ARG -2
+#define WCT_ERR_STATE -3
+#define WCT_ERR_NOMEM -4
+
+void wct_set_error(const char* fmt, ...);
+
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      wct_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),     \
+                    __FILE__, __LINE__);                                       \
+      return WCT_ERR_HIP;                                                      \
+    }                                                                          \
+  } while (0)
+
+#define ARG_CHECK(cond)                                                        \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      wct_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__);\
+      return WCT_ERR_ARG;                                                      \
+    }                                                                          \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- conv.hip -------------------------------------------------------------
+struct ConvArgs {
+  const half_t* x;     // [B][Hin][Win][Cin] fp16 NHWC
+  const half_t* w;     // [Cout][9][Cin] fp16 (tap-major, K contiguous)
+  const float* bias;   // [Cout]
+  half_t* y16;         // [B][H][W][Cout] fp16 or nullptr
+  float* y32;          // [B][H][W][Cout] fp32 or nullptr
+  int B, H, W;         // output size (== input size, or 2x input if upsample)
+  int Cin, Cout;
+  int upsample;        // input is the x2 nearest upsample of x (model.py:293)
+  int relu;
+};
+int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+
+struct ConvFirstArgs {   // 3 -> 64 with the 1x1 'preprocess' folded in
+  const float* x;      // [B][H][W][3] fp32 image in [0,1]
+  const float* w;      // [27][64] folded weights (tap*3+cin major)
+  const float* bias;   // [64]
+  half_t* y16;
+  float* y32;
+  int B, H, W;
+  int clamp01;         // clip(x,0,1) at load (model.py:86)
+};
+int launch_conv_first(const ConvFirstArgs& a, hipStream_t s);
+
+struct ConvLastArgs {    // 64 -> 3, no activation (model.py:298)
+  const half_t* x;     // [B][H][W][64]
+  const float* w;      // [9*64][3] fp32
+  const float* bias;   // [3]
+  float* y;            // [B][H][W][3] fp32, unclipped
+  int B, H, W;
+};
+int launch_conv_last(const ConvLastArgs& a, hipStream_t s);
+
+int launch_maxpool2x2(const half_t* x, half_t* y, int B, int H, int W, int C, hipStream_t s);
+int launch_u8_to_f32(const uint8_t* x, float* y, size_t n, hipStream_t s);       // /255 (wct.py:64)
+int launch_f32_to_u8(const float* x, uint8_t* y, size_t n, hipStream_t s);       // uint8(clip*255) (wct.py:68)
+int launch_f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s);
+int launch_f16_to_f32(const half_t* x, float* y, size_t n, hipStream_t s);
+
+// ---- wct.hip --------------------------------------------------------------
+// Feature matrices are pixel-major: X[n][c] (NHWC flattened), fp32.
+enum { WCT_MODE_NP = 0, WCT_MODE_TF = 1 };
+
+// P independent whiten-colour transforms on `s`:  out = blend(T (x - mc) + ms)
+// content [P][Nc][C], style [P][Ns][C]; out16/out32 [P][Nc][C] (either may be null).
+size_t wct_workspace_bytes(int C, int Nc, int Ns, int P);
+int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P,
+               float alpha, int mode, float eps /* <0: reference default */, half_t* out16, float* out32,
+               void* workspace, size_t workspace_bytes, int* sweeps_dev, int stages, hipStream_t s);
+enum { WCT_STAGE_COV = 1, WCT_STAGE_EIG = 2, WCT_STAGE_APPLY = 4, WCT_STAGE_ALL = 7 };
+int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P,
+                 float alpha, float eps, half_t* out16, float* out32,
+                 void* workspace, size_t workspace_bytes, hipStream_t s);
+// Symmetric eigensolver (batched): A [nmat][C][C] is overwritten (diag -> eigenvalues),
+// V [nmat][C][C] gets eigenvectors in columns.  C multiple of 32, 32 <= C <= 1024.
+int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace,
+                       size_t workspace_bytes, int* sweeps_done_dev, hipStream_t s);
+size_t jacobi_workspace_bytes(int C, int nmat);
+
+// ---- coral.hip ------------------------------------------------------------
+struct CoralApplyArgs {
+  double M[9], src_mean[3], src_std[3], tgt_mean[3], tgt_std[3];
+};
+int launch_coral_stats(const uint8_t* img, size_t npix, unsigned long long* partial, int nblocks,
+                       unsigned long long* out9, hipStream_t s);
+int launch_coral_apply(const uint8_t* src, size_t npix, const CoralApplyArgs& a, uint8_t* out_u8,
+                       double* out_f64, hipStream_t s);

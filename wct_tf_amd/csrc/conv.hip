@@ -1,0 +1,460 @@
+// Convolution stack of the stylize path, hand-written for gfx950 (CDNA4).
+//
+// Replaces what the reference delegates to cuDNN through Keras:
+//   pad_reflect + Conv2D 3x3 'valid' + bias (+ReLU)  (ops.py:12-19, vgg_normalised.py:28-40)
+//   UpSampling2D x2 nearest folded into the loader      (model.py:293)
+//   MaxPooling2D(padding='same')                        (vgg_normalised.py:42)
+//   the 1x1 'preprocess' conv folded into conv1_1       (vgg_normalised.py:25-26)
+//   final 64->3 conv without activation                 (model.py:298)
+//
+// Layout: activations NHWC fp16, weights [Cout][tap][Cin] fp16, fp32 accumulate
+// on v_mfma_f32_32x32x16_f16.  The implicit GEMM is D[cout][pixel] =
+// sum_{tap,cin} W[cout][tap,cin] * X[pixel+tap][cin]  (A = weights, B = pixels),
+// so every lane ends up holding 4 consecutive output channels of one pixel and
+// the epilogue stores 8 B (fp16) / 16 B (fp32) per lane.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// generic 3x3 conv, Cin % 32 == 0, Cout % BN == 0
+// ---------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int TW = 16;          // tile width in pixels (one MFMA B-fragment = 2 rows x 16)
+constexpr int PITCH = 20;       // patch row pitch in pixels (18 used; multiple of 4 keeps the swizzle aligned)
+constexpr int BK = 32;          // input channels per K-chunk
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  // 1-px REFLECT padding (edge not repeated): -1 -> 1, n -> n-2
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  // ragged tiles can run further out; clamp (those lanes are masked at the store)
+  i = i < 0 ? 0 : i;
+  return i >= n ? n - 1 : i;
+}
+
+template <int TH, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
+  constexpr int PH = TH + 2;
+  constexpr int MT = (TH / 2) / WM;          // 32-pixel MFMA tiles per wave
+  constexpr int NT = (BN / 32) / WN;         // 32-channel MFMA tiles per wave
+  constexpr int PATCH_ITEMS = PH * 18 * 4;   // 16-byte pieces per K-chunk
+  constexpr int PATCH_PER_THREAD = (PATCH_ITEMS + 255) / 256;
+  constexpr int W_ITEMS = BN * 4;
+  constexpr int W_PER_THREAD = (W_ITEMS + 255) / 256;
+  constexpr int PATCH_BYTES = PH * PITCH * 64;
+  constexpr int W_BYTES = BN * 64;
+  constexpr int DUMP_OFF = 2 * PATCH_BYTES + 2 * W_BYTES;   // 4 KiB dump area (relative to smem)
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS map: patch buffers at [0, 2*PATCH_BYTES), weight buffers after them
+  auto patch_buf = [&](int i) -> unsigned char* { return smem + i * PATCH_BYTES; };
+  auto w_buf = [&](int i) -> unsigned char* { return smem + 2 * PATCH_BYTES + i * W_BYTES; };
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bid = blockIdx.x;
+  const int ntile = bid % n_tiles;
+  bid /= n_tiles;
+  const int tx = bid % tiles_x;
+  const int ty = bid / tiles_x;
+  const int b = blockIdx.y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int n0 = ntile * BN;
+
+  const int Hin = p.upsample ? p.H / 2 : p.H;
+  const int Win = p.upsample ? p.W / 2 : p.W;
+  const half_t* xb = p.x + (size_t)b * Hin * Win * p.Cin;
+
+  // --- per-thread source offsets of the patch pieces (element offsets, without the chunk base)
+  int patch_src[PATCH_PER_THREAD];
+  int patch_dst[PATCH_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < PATCH_PER_THREAD; ++i) {
+    int item = tid + i * 256;
+    int valid = item < PATCH_ITEMS;
+    int pix = valid ? item >> 2 : 0;
+    int chunk = item & 3;
+    int py = pix / 18, px = pix - py * 18;
+    int iy = reflect_idx(y0 - 1 + py, p.H);
+    int ix = reflect_idx(x0 - 1 + px, p.W);
+    if (p.upsample) { iy >>= 1; ix >>= 1; }
+    // tail lanes past the last piece re-read piece 0 and park it in a dump slot: no branches in the loop
+    patch_src[i] = valid ? (iy * Win + ix) * p.Cin + chunk * 8 : 0;
+    patch_dst[i] = valid ? ((py * PITCH + px) * 4 + (chunk ^ ((px >> 2) & 3))) * 16 : DUMP_OFF + tid * 16;
+  }
+  int w_src[W_PER_THREAD];
+  int w_dst[W_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < W_PER_THREAD; ++i) {
+    int item = tid + i * 256;
+    int valid = item < W_ITEMS;
+    int n = valid ? item >> 2 : 0;
+    int chunk = item & 3;
+    w_src[i] = valid ? (n0 + n) * 9 * p.Cin + chunk * 8 : 0;
+    w_dst[i] = valid ? (n * 4 + (chunk ^ ((n >> 2) & 3))) * 16 : DUMP_OFF + tid * 16;
+  }
+
+  // --- fragment read offsets
+  // B (pixels): lane -> pixel (row (l&31)>>4, col l&15), k-group l>>5
+  const int frag_px = lane & 15;
+  const int frag_py = (lane & 31) >> 4;
+  const int kgrp = lane >> 5;
+  // A (weights): lane -> channel l&31, k-group l>>5
+  int a_off[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = (wn * NT + nt) * 32 + (lane & 31);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      int chunk = ks * 2 + kgrp;
+      a_off[nt][ks] = (n * 4 + (chunk ^ ((n >> 2) & 3))) * 16;
+    }
+  }
+
+  f32x16 acc[NT][MT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+
+  const int n_chunks = p.Cin / BK;
+  const int n_iter = n_chunks * 9;
+
+  u32x4 patch_regs[PATCH_PER_THREAD];
+  u32x4 w_regs[W_PER_THREAD];
+
+  // prologue: chunk 0 patch + tap 0 weights
+#pragma unroll
+  for (int i = 0; i < PATCH_PER_THREAD; ++i)
+    patch_regs[i] = *reinterpret_cast<const u32x4*>(xb + patch_src[i]);
+#pragma unroll
+  for (int i = 0; i < W_PER_THREAD; ++i)
+    w_regs[i] = *reinterpret_cast<const u32x4*>(p.w + w_src[i]);
+#pragma unroll
+  for (int i = 0; i < PATCH_PER_THREAD; ++i)
+    *reinterpret_cast<u32x4*>(smem + patch_dst[i]) = patch_regs[i];
+#pragma unroll
+  for (int i = 0; i < W_PER_THREAD; ++i)
+    *reinterpret_cast<u32x4*>(smem + 2 * PATCH_BYTES + w_dst[i]) = w_regs[i];
+  __syncthreads();
+
+  int pbuf = 0;
+  for (int it = 0; it < n_iter; ++it) {
+    const int chunk_i = it / 9;
+    const int tap = it - chunk_i * 9;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int wbuf = it & 1;
+    const bool has_next = it + 1 < n_iter;
+    const bool next_patch = has_next && tap == 8;
+
+    // 1) issue the global loads of the next stage
+    if (has_next) {
+      const int ntap = tap == 8 ? 0 : tap + 1;
+      const int nchunk = tap == 8 ? chunk_i + 1 : chunk_i;
+      const int wbase = ntap * p.Cin + nchunk * BK;
+#pragma unroll
+      for (int i = 0; i < W_PER_THREAD; ++i)
+        w_regs[i] = *reinterpret_cast<const u32x4*>(p.w + w_src[i] + wbase);
+      if (next_patch) {
+        const int cbase = nchunk * BK;
+#pragma unroll
+        for (int i = 0; i < PATCH_PER_THREAD; ++i)
+          patch_regs[i] = *reinterpret_cast<const u32x4*>(xb + patch_src[i] + cbase);
+      }
+    }
+
+    // 2) MFMAs on the current stage
+    const unsigned char* pl = patch_buf(pbuf);
+    const unsigned char* wl = w_buf(wbuf);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 afrag[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) afrag[nt] = *reinterpret_cast<const half8*>(wl + a_off[nt][ks]);
+      const int chunk = ks * 2 + kgrp;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int py = (wm * MT + mt) * 2 + frag_py + ky;
+        const int px = frag_px + kx;
+        const int off = ((py * PITCH + px) * 4 + (chunk ^ ((px >> 2) & 3))) * 16;
+        half8 bfrag = *reinterpret_cast<const half8*>(pl + off);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[nt], bfrag, acc[nt][mt], 0, 0, 0);
+      }
+    }
+
+    // 3) park the prefetched stage in the other LDS buffers
+    if (has_next) {
+#pragma unroll
+      for (int i = 0; i < W_PER_THREAD; ++i)
+        *reinterpret_cast<u32x4*>(smem + 2 * PATCH_BYTES + (wbuf ^ 1) * W_BYTES * (w_dst[i] < DUMP_OFF) + w_dst[i]) = w_regs[i];
+      if (next_patch) {
+#pragma unroll
+        for (int i = 0; i < PATCH_PER_THREAD; ++i)
+          *reinterpret_cast<u32x4*>(smem + (pbuf ^ 1) * PATCH_BYTES * (patch_dst[i] < DUMP_OFF) + patch_dst[i]) = patch_regs[i];
+        pbuf ^= 1;
+      }
+    }
+    __syncthreads();
+  }
+
+  // --- epilogue: bias, ReLU, store.  acc register r of a 32x32 tile holds
+  // channel (r&3) + 8*(r>>2) + 4*(lane>>5) of pixel lane&31.
+  const size_t out_base = (size_t)b * p.H * p.W;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int oy = y0 + (wm * MT + mt) * 2 + frag_py;
+    const int ox = x0 + frag_px;
+    const bool inside = oy < p.H && ox < p.W;
+    const size_t pix = out_base + (size_t)oy * p.W + ox;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int co = n0 + (wn * NT + nt) * 32 + 8 * rq + 4 * kgrp;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = acc[nt][mt][rq * 4 + j] + bv[j];
+          v[j] = p.relu ? fmaxf(t, 0.f) : t;
+        }
+        if (inside) {
+          if (p.y16) {
+            half4 h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
+            *reinterpret_cast<half4*>(p.y16 + pix * p.Cout + co) = h;
+          }
+          if (p.y32) *reinterpret_cast<f32x4*>(p.y32 + pix * p.Cout + co) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TH, int BN, int WM, int WN>
+static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
+  const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
+  const int n_tiles = a.Cout / BN;
+  constexpr int PH = TH + 2;
+  const size_t lds = 2 * (size_t)PH * PITCH * 64 + 2 * (size_t)BN * 64 + 4096;
+  dim3 grid(tiles_x * tiles_y * n_tiles, a.B);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
+  ARG_CHECK(a.Cin % BK == 0 && a.Cout % 64 == 0 && a.H > 1 && a.W > 1 && a.B > 0);
+  ARG_CHECK(!a.upsample || (a.H % 2 == 0 && a.W % 2 == 0));
+  // pick the largest tile that still gives the chip >= ~1 block per CU
+  const long px16 = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.B;
+  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_conv_cfg<16, 128, 2, 2>(a, s);
+  if (px16 * (a.Cout / 64) >= 256) return launch_conv_cfg<16, 64, 4, 1>(a, s);
+  return launch_conv_cfg<8, 64, 2, 2>(a, s);
+}
+
+// ---------------------------------------------------------------------------
+// conv1_1: 3 -> 64, fp32 image in, VALU direct conv (K = 27 is too thin for MFMA;
+// the layer is bound by its 64-channel output write)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int tiles_x) {
+  __shared__ float patch[18][18][3];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int b = blockIdx.y;
+  const int y0 = ty * 16, x0 = tx * 16;
+  const float* xb = p.x + (size_t)b * p.H * p.W * 3;
+  for (int i = tid; i < 18 * 18 * 3; i += 256) {
+    int c = i % 3, pix = i / 3;
+    int py = pix / 18, px = pix - py * 18;
+    int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
+    float v = xb[((size_t)iy * p.W + ix) * 3 + c];
+    if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    patch[py][px][c] = v;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int oy = y0 + ly, ox = x0 + lx;
+  float in[27];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) in[(ky * 3 + kx) * 3 + c] = patch[ly + ky][lx + kx][c];
+  if (oy >= p.H || ox >= p.W) return;
+  const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+#pragma unroll 1
+  for (int cg = 0; cg < 8; ++cg) {       // 8 channels at a time keeps the accumulators in registers
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = p.bias[cg * 8 + j];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(in[k], p.w[k * 64 + cg * 8 + j], acc[j]);   // uniform address -> scalar loads
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    if (p.y16) {
+      half8 h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (half_t)acc[j];
+      *reinterpret_cast<half8*>(p.y16 + pix * 64 + cg * 8) = h;
+    }
+    if (p.y32) {
+      f32x4 v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
+      *reinterpret_cast<f32x4*>(p.y32 + pix * 64 + cg * 8) = v0;
+      *reinterpret_cast<f32x4*>(p.y32 + pix * 64 + cg * 8 + 4) = v1;
+    }
+  }
+}
+
+int launch_conv_first(const ConvFirstArgs& a, hipStream_t s) {
+  ARG_CHECK(a.H > 1 && a.W > 1 && a.B > 0);
+  const int tiles_x = cdiv(a.W, 16), tiles_y = cdiv(a.H, 16);
+  hipLaunchKernelGGL(conv_first_kernel, dim3(tiles_x * tiles_y, a.B), dim3(256), 0, s, a, tiles_x);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// decoder output conv: 64 -> 3, no activation, fp32 out (bound by the 64-ch read)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_last_kernel(ConvLastArgs p, int tiles_x) {
+  // patch [18][18] pixels x 64 ch fp16 = 128 B per pixel, 16-B pieces XOR-swizzled
+  __shared__ __attribute__((aligned(16))) unsigned char patch[18 * 18 * 128];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int b = blockIdx.y;
+  const int y0 = ty * 16, x0 = tx * 16;
+  const half_t* xb = p.x + (size_t)b * p.H * p.W * 64;
+  for (int item = tid; item < 18 * 18 * 8; item += 256) {
+    int pix = item >> 3, chunk = item & 7;
+    int py = pix / 18, px = pix - py * 18;
+    int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
+    uint4 v = *reinterpret_cast<const uint4*>(xb + ((size_t)iy * p.W + ix) * 64 + chunk * 8);
+    *reinterpret_cast<uint4*>(patch + (pix * 8 + (chunk ^ ((px >> 1) & 7))) * 16) = v;
+  }
+  __syncthreads();
+  const int ly = tid >> 4, lx = tid & 15;
+  const int oy = y0 + ly, ox = x0 + lx;
+  float a0 = p.bias[0], a1 = p.bias[1], a2 = p.bias[2];
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int py = ly + ky, px = lx + kx;
+    const int pix = py * 18 + px;
+#pragma unroll
+    for (int chunk = 0; chunk < 8; ++chunk) {
+      half8 h = *reinterpret_cast<const half8*>(patch + (pix * 8 + (chunk ^ ((px >> 1) & 7))) * 16);
+      const float* wk = p.w + (tap * 64 + chunk * 8) * 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float xv = (float)h[j];
+        a0 = fmaf(xv, wk[j * 3 + 0], a0);
+        a1 = fmaf(xv, wk[j * 3 + 1], a1);
+        a2 = fmaf(xv, wk[j * 3 + 2], a2);
+      }
+    }
+  }
+  if (oy < p.H && ox < p.W) {
+    float* o = p.y + (((size_t)b * p.H + oy) * p.W + ox) * 3;
+    o[0] = a0; o[1] = a1; o[2] = a2;
+  }
+}
+
+int launch_conv_last(const ConvLastArgs& a, hipStream_t s) {
+  ARG_CHECK(a.H > 1 && a.W > 1 && a.B > 0);
+  const int tiles_x = cdiv(a.W, 16), tiles_y = cdiv(a.H, 16);
+  hipLaunchKernelGGL(conv_last_kernel, dim3(tiles_x * tiles_y, a.B), dim3(256), 0, s, a, tiles_x);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 2x2/2 max-pool, 'same' (= ceil mode): the odd last row/col pools what exists
+// ---------------------------------------------------------------------------
+__global__ void maxpool_kernel(const half_t* x, half_t* y, int B, int H, int W, int C, int Ho, int Wo) {
+  const int c8 = C / 8;
+  size_t total = (size_t)B * Ho * Wo * c8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % c8);
+    size_t t = i / c8;
+    int ox = (int)(t % Wo); t /= Wo;
+    int oy = (int)(t % Ho);
+    int b = (int)(t / Ho);
+    const half_t* xb = x + (size_t)b * H * W * C;
+    int iy = oy * 2, ix = ox * 2;
+    half8 m = *reinterpret_cast<const half8*>(xb + ((size_t)iy * W + ix) * C + c * 8);
+    if (ix + 1 < W) m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(xb + ((size_t)iy * W + ix + 1) * C + c * 8));
+    if (iy + 1 < H) {
+      m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(xb + ((size_t)(iy + 1) * W + ix) * C + c * 8));
+      if (ix + 1 < W) m = __builtin_elementwise_max(m, *reinterpret_cast<const half8*>(xb + ((size_t)(iy + 1) * W + ix + 1) * C + c * 8));
+    }
+    *reinterpret_cast<half8*>(y + i * 8) = m;
+  }
+}
+
+int launch_maxpool2x2(const half_t* x, half_t* y, int B, int H, int W, int C, hipStream_t s) {
+  ARG_CHECK(C % 8 == 0);
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  size_t total = (size_t)B * Ho * Wo * (C / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, s, x, y, B, H, W, C, Ho, Wo);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dtype / range conversions at the path boundary (wct.py:60-68)
+// ---------------------------------------------------------------------------
+__global__ void u8_to_f32_kernel(const uint8_t* x, float* y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    y[i] = (float)((double)x[i] / 255.0);    // image / 255. in float64, then the fp32 feed cast
+}
+__global__ void f32_to_u8_kernel(const float* x, uint8_t* y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float v = fminf(fmaxf(x[i], 0.f), 1.f) * 255.f;
+    y[i] = (uint8_t)v;                       // np.uint8() truncates
+  }
+}
+__global__ void f32_to_f16_kernel(const float* x, half_t* y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (half_t)x[i];
+}
+__global__ void f16_to_f32_kernel(const half_t* x, float* y, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+
+static inline int ew_blocks(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b ? b : 1));
+}
+int launch_u8_to_f32(const uint8_t* x, float* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+int launch_f32_to_u8(const float* x, uint8_t* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_u8_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+int launch_f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+int launch_f16_to_f32(const half_t* x, float* y, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, x, y, n);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}

@@ -1,0 +1,657 @@
+// Whiten-colour transform (and AdaIN) for gfx950, replacing ops.py:24-140,282-294.
+//
+// Feature maps stay pixel-major (NHWC flattened: X[n][c], fp32) so none of the
+// reference's four transposes exist.  Per transform:
+//   K3  colstats      per-channel mean (two-stage, deterministic)
+//   K4  cov           C x C covariance of the centred features, split-K on
+//                     v_mfma_f32_32x32x2_f32 (exact fp32), mean subtracted at load
+//   K5  jacobi        batched two-sided block-Jacobi eigensolver (content+style together)
+//   K6  tbuild        T = E_s f_s(L_s) E_s^T . E_c f_c(L_c) E_c^T with the 1e-5 cut-off
+//   K7  apply         out = (x - mc) M^T + b,  M = alpha T + (1-alpha) I  (one GEMM,
+//                     blend and re-centring folded into M and b)
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// K3: per-channel sums over the pixel axis
+// ---------------------------------------------------------------------------
+// grid (nslab, 2P): matrix m = 2*pair + side (0 content, 1 style); slab s reduces rows
+// [s*rows_per_slab, ...) of X_m[N_side][C]
+struct StatArgs {
+  const float* x[2];     // content base [P][Nc][C], style base [P][Ns][C]
+  int n[2];
+  const float* mean;     // [2P][C] or null; if set, accumulate (x-mean)^2 instead of x
+  float* partial;        // [2P][nslab][C]
+  int C, nslab;
+};
+
+__global__ __launch_bounds__(256) void colsum_kernel(StatArgs p) {
+  __shared__ f32x4 red[256];
+  const int mat = blockIdx.y, slab = blockIdx.x;
+  const int b = mat & 1, pair = mat >> 1;
+  const int C = p.C, cq = C / 4;
+  const int nrp = 256 / cq;                  // rows handled in parallel (C <= 1024)
+  const int tid = threadIdx.x;
+  const int rp = tid / cq, c4 = tid % cq;
+  const int N = p.n[b];
+  const int rows_per_slab = (N + p.nslab - 1) / p.nslab;
+  const int r0 = slab * rows_per_slab;
+  const int r1 = min(N, r0 + rows_per_slab);
+  const float* x = p.x[b] + (size_t)pair * N * C;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};
+  if (p.mean) m = *reinterpret_cast<const f32x4*>(p.mean + mat * C + c4 * 4);
+  if (rp < nrp) {
+    for (int r = r0 + rp; r < r1; r += nrp) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + c4 * 4);
+      if (p.mean) { v -= m; acc += v * v; } else acc += v;
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  if (rp == 0) {
+    for (int j = 1; j < nrp; ++j) acc += red[j * cq + c4];
+    *reinterpret_cast<f32x4*>(p.partial + ((size_t)mat * p.nslab + slab) * C + c4 * 4) = acc;
+  }
+}
+
+// out[m][c] = sum_slab partial / denom_side
+__global__ void colsum_finish_kernel(const float* partial, float* out, int C, int nslab, float d0, float d1) {
+  const int mat = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < nslab; ++i) s += partial[((size_t)mat * nslab + i) * C + c];
+  out[mat * C + c] = s / ((mat & 1) == 0 ? d0 : d1);
+}
+
+// ---------------------------------------------------------------------------
+// generic fp32 GEMM tile on v_mfma_f32_32x32x2_f32
+//   D[m][n] = sum_k A(m,k) B(k,n)
+// A element (m,k): a_kmajor ? A[k*lda+m] : A[m*lda+k];  B element (k,n): b_kmajor ? B[k*ldb+n] : B[n*ldb+k]
+// ---------------------------------------------------------------------------
+struct GemmArgs {
+  const float* A; int lda; int a_kmajor;
+  const float* B; int ldb; int b_kmajor;
+  const float* a_sub_m;   // subtract vector indexed by m from A (cov centring)       or null
+  const float* b_sub_n;   // subtract vector indexed by n from B                      or null
+  const float* a_sub_k;   // subtract vector indexed by k from A (apply centring)     or null
+  const float* a_scale_k; // scale A by vector indexed by k (E diag(d))               or null
+  int M, N, K;
+  int ksplit;             // K elements per blockIdx.z slice (multiple of 16)
+  float* out32; half_t* out16; int ldo;
+  size_t out_split_stride;  // elements between K-slices of out32 (split-K partials)
+  const float* bias_n;    // added per output column or null
+  // batching: blockIdx.z = batch * nsplit + split; strides in elements (0 = shared)
+  int nsplit;
+  size_t sA, sB, s_sub_m, s_sub_n, s_sub_k, s_scale_k, s_out, s_bias;
+};
+
+constexpr int GK = 16;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+  constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave (2x2 waves)
+  constexpr int PA = BM + 4, PB = BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[GK][PA];
+  __shared__ __attribute__((aligned(16))) float Bs[GK][PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int batch = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
+  const int kbeg = split * p.ksplit;
+  const int kend = min(p.K, kbeg + p.ksplit);
+  p.A += batch * p.sA; p.B += batch * p.sB;
+  if (p.a_sub_m) p.a_sub_m += batch * p.s_sub_m;
+  if (p.b_sub_n) p.b_sub_n += batch * p.s_sub_n;
+  if (p.a_sub_k) p.a_sub_k += batch * p.s_sub_k;
+  if (p.a_scale_k) p.a_scale_k += batch * p.s_scale_k;
+  if (p.bias_n) p.bias_n += batch * p.s_bias;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    // ---- stage A tile: As[k][m]
+    if (p.a_kmajor) {
+      for (int item = tid; item < GK * BM / 4; item += 256) {
+        int k = item / (BM / 4), m4 = item % (BM / 4);
+        int gk = k0 + k, gm = m0 + m4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < kend && gm < p.M) {
+          v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gk * p.lda + gm);
+          if (p.a_sub_m) v -= *reinterpret_cast<const f32x4*>(p.a_sub_m + gm);
+        }
+        *reinterpret_cast<f32x4*>(&As[k][m4 * 4]) = v;
+      }
+    } else {
+      for (int item = tid; item < BM * GK / 4; item += 256) {
+        int m = item / (GK / 4), k4 = item % (GK / 4);
+        int gm = m0 + m, gk = k0 + k4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gm < p.M && gk < kend) {     // K and ksplit are multiples of 4
+          v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gm * p.lda + gk);
+          if (p.a_sub_k) v -= *reinterpret_cast<const f32x4*>(p.a_sub_k + gk);
+          if (p.a_scale_k) v *= *reinterpret_cast<const f32x4*>(p.a_scale_k + gk);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) As[k4 * 4 + j][m] = v[j];
+      }
+    }
+    // ---- stage B tile: Bs[k][n]
+    if (p.b_kmajor) {
+      for (int item = tid; item < GK * BN / 4; item += 256) {
+        int k = item / (BN / 4), n4 = item % (BN / 4);
+        int gk = k0 + k, gn = n0 + n4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gk < kend && gn < p.N) {
+          v = *reinterpret_cast<const f32x4*>(p.B + (size_t)gk * p.ldb + gn);
+          if (p.b_sub_n) v -= *reinterpret_cast<const f32x4*>(p.b_sub_n + gn);
+        }
+        *reinterpret_cast<f32x4*>(&Bs[k][n4 * 4]) = v;
+      }
+    } else {
+      for (int item = tid; item < BN * GK / 4; item += 256) {
+        int n = item / (GK / 4), k4 = item % (GK / 4);
+        int gn = n0 + n, gk = k0 + k4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (gn < p.N && gk < kend) v = *reinterpret_cast<const f32x4*>(p.B + (size_t)gn * p.ldb + gk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[k4 * 4 + j][n] = v[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 2) {
+      float a[TM], b[TN];
+      const int kr = kk + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kr][(wm * TM + i) * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kr][(wn * TN + j) * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: reg r of a tile = row (r&3)+8*(r>>2)+4*(lane>>5), col lane&31
+  float* o32 = p.out32 ? p.out32 + batch * p.s_out + (size_t)split * p.out_split_stride : nullptr;
+  half_t* o16 = p.out16 ? p.out16 + batch * p.s_out : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+      const float bias = (p.bias_n && gn < p.N) ? p.bias_n[gn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm < p.M && gn < p.N) {
+          float v = acc[i][j][r] + bias;
+          if (o32) o32[(size_t)gm * p.ldo + gn] = v;
+          if (o16) o16[(size_t)gm * p.ldo + gn] = (half_t)v;
+        }
+      }
+    }
+}
+
+static int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s) {
+  g.nsplit = nsplit;
+  const int gz = nsplit * nbatch;
+  if (g.M >= 128 && g.N >= 128) {
+    dim3 grid(cdiv(g.N, 128), cdiv(g.M, 128), gz);
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, s, g);
+  } else if (g.M >= 128) {
+    dim3 grid(cdiv(g.N, 64), cdiv(g.M, 128), gz);
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 64>), grid, dim3(256), 0, s, g);
+  } else {
+    dim3 grid(cdiv(g.N, 64), cdiv(g.M, 64), gz);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, s, g);
+  }
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// cov[b] = sum_split partial / (N_b - 1) + eps I
+__global__ void cov_finish_kernel(const float* partial, float* cov, int C, int nsplit, float inv0, float inv1, float eps) {
+  const int mat = blockIdx.y;             // 2*pair + side
+  const size_t cc = (size_t)C * C;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= cc) return;
+  const float* pb = partial + (size_t)mat * nsplit * cc;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += pb[(size_t)k * cc + i];
+  s *= ((mat & 1) == 0 ? inv0 : inv1);
+  if (i / C == i % C) s += eps;
+  cov[(size_t)mat * cc + i] = s;
+}
+
+// ---------------------------------------------------------------------------
+// K5: batched symmetric eigensolver -- two-sided block Jacobi.
+//   blocks of 16 columns, round-robin over block pairs; each pair's 32x32
+//   diagonal problem gets one cyclic Jacobi sweep in LDS (jacobi_diag_kernel),
+//   then every 32x32 tile of A (and of the eigenvector matrix V) is updated as
+//   Qg^T A_gh Qh on fp32 MFMA (jacobi_update_kernel).  Two launches per step,
+//   C/16-1 steps per sweep.  A per-matrix `done` flag turns later launches into no-ops.
+// ---------------------------------------------------------------------------
+struct JacobiState {
+  unsigned int offmax;   // max |a_pq|/sqrt(a_pp a_qq) seen this sweep (float bits)
+  int done;
+  int sweeps;
+  int pad;
+};
+
+__device__ __forceinline__ int rr_idx(int pos, int step, int n) {
+  // circle method: position 0 is fixed, the other n-1 rotate
+  return pos == 0 ? 0 : ((pos - 1 + step) % (n - 1)) + 1;
+}
+
+__device__ __forceinline__ int pair_index(int r, int bi, int bj) {
+  return r < 16 ? bi * 16 + r : bj * 16 + (r - 16);
+}
+
+constexpr float JACOBI_ROT_TOL = 1e-6f;    // skip rotations below this relative size
+constexpr float JACOBI_CONV_TOL = 3e-5f;   // a sweep that never saw more than this is the last one
+constexpr float JACOBI_FLOOR = 1e-6f;      // both diagonals below this: the pair cannot reach the 1e-5 cut-off
+
+__global__ __launch_bounds__(256) void jacobi_diag_kernel(float* A, float* Qbuf, JacobiState* st, int C, int step) {
+  const int m = blockIdx.y, g = blockIdx.x;
+  if (st[m].done) return;
+  __shared__ float S[32][33];
+  __shared__ float Q[32][33];
+  __shared__ float cs[16][2];
+  __shared__ int pq[16][2];
+  __shared__ float offs[16];
+  const int tid = threadIdx.x;
+  const int nblk = C / 16, npair = nblk / 2;
+  const int bi = rr_idx(g, step, nblk), bj = rr_idx(nblk - 1 - g, step, nblk);
+  float* Am = A + (size_t)m * C * C;
+  for (int e = tid; e < 1024; e += 256) {
+    int r = e >> 5, c = e & 31;
+    S[r][c] = Am[(size_t)pair_index(r, bi, bj) * C + pair_index(c, bi, bj)];
+    Q[r][c] = r == c ? 1.f : 0.f;
+  }
+  float my_off = 0.f;
+  __syncthreads();
+  for (int s = 0; s < 31; ++s) {
+    if (tid < 16) {
+      const int p = rr_idx(tid, s, 32), q = rr_idx(31 - tid, s, 32);
+      const float app = S[p][p], aqq = S[q][q], apq = S[p][q];
+      const float den = sqrtf(fabsf(app * aqq));
+      float c = 1.f, sn = 0.f;
+      const bool live = fabsf(app) + fabsf(aqq) > JACOBI_FLOOR;
+      if (live && fabsf(apq) > JACOBI_ROT_TOL * den && fabsf(apq) > 1e-36f) {
+        my_off = fmaxf(my_off, den > 0.f ? fabsf(apq) / den : 1.f);
+        const float zeta = (aqq - app) / (2.f * apq);
+        const float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+        c = 1.f / sqrtf(1.f + t * t);
+        sn = c * t;
+      }
+      cs[tid][0] = c; cs[tid][1] = sn;
+      pq[tid][0] = p; pq[tid][1] = q;
+    }
+    __syncthreads();
+    {
+      const int k = tid >> 4, l = tid & 15;
+      const int pk = pq[k][0], qk = pq[k][1], pl = pq[l][0], ql = pq[l][1];
+      const float ck = cs[k][0], sk = cs[k][1], cl = cs[l][0], sl = cs[l][1];
+      const float xpp = S[pk][pl], xpq = S[pk][ql], xqp = S[qk][pl], xqq = S[qk][ql];
+      // columns (pair l), then rows (pair k)
+      const float ypp = cl * xpp - sl * xpq, ypq = sl * xpp + cl * xpq;
+      const float yqp = cl * xqp - sl * xqq, yqq = sl * xqp + cl * xqq;
+      S[pk][pl] = ck * ypp - sk * yqp;
+      S[pk][ql] = ck * ypq - sk * yqq;
+      S[qk][pl] = sk * ypp + ck * yqp;
+      S[qk][ql] = sk * ypq + ck * yqq;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = k + 16 * i;
+        const float qp = Q[r][pl], qq = Q[r][ql];
+        Q[r][pl] = cl * qp - sl * qq;
+        Q[r][ql] = sl * qp + cl * qq;
+      }
+    }
+    __syncthreads();
+  }
+  float* Qo = Qbuf + ((size_t)m * npair + g) * 1024;
+  for (int e = tid; e < 1024; e += 256) Qo[e] = Q[e >> 5][e & 31];
+  if (tid < 16) offs[tid] = my_off;
+  __syncthreads();
+  if (tid == 0) {
+    float mx = 0.f;
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, offs[i]);
+    atomicMax(&st[m].offmax, __float_as_uint(mx));
+  }
+}
+
+// grid (2*npair*npair, nmat), one wave per 32x32 tile.
+__global__ __launch_bounds__(64) void jacobi_update_kernel(float* A, float* V, const float* Qbuf, const JacobiState* st, int C, int step) {
+  const int m = blockIdx.y;
+  if (st[m].done) return;
+  __shared__ float Xs[32][33];
+  __shared__ float Qh[32][33];
+  __shared__ float Qg[32][33];
+  const int lane = threadIdx.x;
+  const int nblk = C / 16, npair = nblk / 2;
+  int t = blockIdx.x;
+  const bool is_v = t >= npair * npair;
+  if (is_v) t -= npair * npair;
+  const int g = t / npair, h = t % npair;       // for V tiles g is the 32-row block index
+  const int hi = rr_idx(h, step, nblk), hj = rr_idx(nblk - 1 - h, step, nblk);
+  int gi = 0, gj = 0;
+  if (!is_v) { gi = rr_idx(g, step, nblk); gj = rr_idx(nblk - 1 - g, step, nblk); }
+  float* X = (is_v ? V : A) + (size_t)m * C * C;
+  const float* Qhp = Qbuf + ((size_t)m * npair + h) * 1024;
+  const float* Qgp = Qbuf + ((size_t)m * npair + g) * 1024;
+  for (int e = lane; e < 1024; e += 64) {
+    const int r = e >> 5, c = e & 31;
+    const int gr = is_v ? g * 32 + r : pair_index(r, gi, gj);
+    Xs[r][c] = X[(size_t)gr * C + pair_index(c, hi, hj)];
+    Qh[r][c] = Qhp[e];
+    if (!is_v) Qg[r][c] = Qgp[e];
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int li = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 32; kk += 2)      // T = X . Qh
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[li][kk + lk], Qh[kk + lk][li], acc, 0, 0, 0);
+  if (!is_v) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Xs[(r & 3) + 8 * (r >> 2) + 4 * lk][li] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2)    // Y = Qg^T . T
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qg[kk + lk][li], Xs[kk + lk][li], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+    const int gr = is_v ? g * 32 + row : pair_index(row, gi, gj);
+    X[(size_t)gr * C + pair_index(li, hi, hj)] = acc[r];
+  }
+}
+
+__global__ void jacobi_init_kernel(float* V, JacobiState* st, int C) {
+  const int m = blockIdx.y;
+  const size_t cc = (size_t)C * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x)
+    V[(size_t)m * cc + i] = (i / C == i % C) ? 1.f : 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st[m].offmax = 0u; st[m].done = 0; st[m].sweeps = 0; st[m].pad = 0; }
+}
+
+__global__ void jacobi_check_kernel(JacobiState* st, int nmat) {
+  const int m = threadIdx.x;
+  if (m >= nmat || st[m].done) return;
+  st[m].sweeps += 1;
+  if (__uint_as_float(st[m].offmax) < JACOBI_CONV_TOL) st[m].done = 1;
+  st[m].offmax = 0u;
+}
+
+__global__ void jacobi_export_sweeps_kernel(const JacobiState* st, int* out, int nmat) {
+  if ((int)threadIdx.x < nmat) out[threadIdx.x] = st[threadIdx.x].sweeps;
+}
+
+constexpr int JACOBI_MAX_SWEEPS = 12;
+
+size_t jacobi_workspace_bytes(int C, int nmat) {
+  return (size_t)nmat * (C / 32) * 1024 * sizeof(float) + 256 + (size_t)nmat * sizeof(JacobiState);
+}
+
+int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
+                       int* sweeps_done_dev, hipStream_t s) {
+  ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
+  ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
+  float* Qbuf = reinterpret_cast<float*>(workspace);
+  size_t qbytes = (size_t)nmat * (C / 32) * 1024 * sizeof(float);
+  JacobiState* st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
+  const int nblk = C / 16, npair = nblk / 2;
+  hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, nmat), dim3(256), 0, s, V, st, C);
+  for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+    for (int step = 0; step < nblk - 1; ++step) {
+      hipLaunchKernelGGL(jacobi_diag_kernel, dim3(npair, nmat), dim3(256), 0, s, A, Qbuf, st, C, step);
+      hipLaunchKernelGGL(jacobi_update_kernel, dim3(2 * npair * npair, nmat), dim3(64), 0, s, A, V, Qbuf, st, C, step);
+    }
+    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, s, st, nmat);
+  }
+  if (sweeps_done_dev) hipLaunchKernelGGL(jacobi_export_sweeps_kernel, dim3(1), dim3(64), 0, s, st, sweeps_done_dev, nmat);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K6: spectral functions with the reference cut-off
+// ---------------------------------------------------------------------------
+// d[2p][k] = whitening gain of content eigenvalue k, d[2p+1][k] = colouring gain of style eigenvalue k
+__global__ void spectral_gain_kernel(const float* A, float* d, int C, int mode, float eps_np) {
+  const int mat = blockIdx.y;
+  const int b = mat & 1;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= C) return;
+  const float lam = A[(size_t)mat * C * C + (size_t)k * C + k];
+  float v = 0.f;
+  if (lam > 1e-5f) {                       // ops.py:68-69 / ops.py:112,125
+    if (mode == WCT_MODE_NP) {
+      const float e = lam + eps_np;        // wct_np eps, default 1e-5 (ops.py:92,114,127)
+      v = b == 0 ? 1.f / sqrtf(e) : sqrtf(e);
+    } else {
+      v = b == 0 ? 1.f / sqrtf(lam) : sqrtf(lam);   // ops.py:72,76
+    }
+  }
+  d[mat * C + k] = v;
+}
+
+// M = alpha T + (1-alpha) I ; bias = alpha ms (+ (1-alpha) mc in tf mode)
+__global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo, float* bias, int C, float alpha, int mode) {
+  const int pair = blockIdx.y;
+  const size_t cc = (size_t)C * C;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < cc) {
+    float v = alpha * T[pair * cc + i];
+    if (i / C == i % C) v += 1.f - alpha;
+    Mo[pair * cc + i] = v;
+  }
+  if (i < (size_t)C) {
+    const float* mp = mean + (size_t)pair * 2 * C;
+    float b = alpha * mp[C + i];
+    if (mode == WCT_MODE_TF) b += (1.f - alpha) * mp[i];
+    bias[pair * C + i] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// workspace carving (P independent content/style pairs per call)
+// ---------------------------------------------------------------------------
+static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WctCarve {
+  float *mean, *var, *stat_partial, *cov_partial, *A, *V, *d, *Tw, *Tcs, *T, *M, *bias;
+  void* jacobi_ws; size_t jacobi_bytes;
+  int nslab, nsplit, ksplit;
+  size_t total;
+};
+
+static int wct_nslab(int N) { int s = cdiv(N, 64); return s < 1 ? 1 : (s > 256 ? 256 : s); }
+
+static void cov_split(int C, int Nmax, int P, int* nsplit, int* ksplit) {
+  const int tiles = (C >= 128 ? (C / 128) * (C / 128) : 1) * P;
+  int want = 512 / tiles;                      // ~2 waves of blocks over 256 CUs
+  if (want < 1) want = 1;
+  int ks = cdiv(cdiv(Nmax, want), GK) * GK;
+  if (ks < 256) ks = 256;
+  *ksplit = ks;
+  *nsplit = cdiv(Nmax, ks);
+}
+
+static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
+  WctCarve w;
+  const int Nmax = Nc > Ns ? Nc : Ns;
+  w.nslab = wct_nslab(Nmax);
+  cov_split(C, Nmax, P, &w.nsplit, &w.ksplit);
+  size_t off = 0;
+  char* b = reinterpret_cast<char*>(base);
+  auto take = [&](size_t bytes) { void* p = b ? b + off : nullptr; off += align_up(bytes); return p; };
+  const size_t cc = (size_t)C * C * sizeof(float);
+  w.mean = (float*)take((size_t)2 * P * C * sizeof(float));
+  w.var = (float*)take((size_t)2 * P * C * sizeof(float));
+  w.stat_partial = (float*)take((size_t)2 * P * w.nslab * C * sizeof(float));
+  w.cov_partial = (float*)take((size_t)2 * P * w.nsplit * cc);
+  w.A = (float*)take(2 * P * cc);
+  w.V = (float*)take(2 * P * cc);
+  w.d = (float*)take((size_t)2 * P * C * sizeof(float));
+  w.Tw = (float*)take(P * cc);
+  w.Tcs = (float*)take(P * cc);
+  w.T = (float*)take(P * cc);
+  w.M = (float*)take(P * cc);
+  w.bias = (float*)take((size_t)P * C * sizeof(float));
+  w.jacobi_bytes = jacobi_workspace_bytes(C, 2 * P);
+  w.jacobi_ws = take(w.jacobi_bytes);
+  w.total = off;
+  return w;
+}
+
+size_t wct_workspace_bytes(int C, int Nc, int Ns, int P) {
+  return carve(nullptr, C < 32 ? 32 : C, Nc, Ns, P).total;
+}
+
+static int launch_means(const float* content, int Nc, const float* style, int Ns, int C, int P,
+                        const WctCarve& w, bool with_var, hipStream_t s) {
+  StatArgs sa;
+  sa.x[0] = content; sa.x[1] = style; sa.n[0] = Nc; sa.n[1] = Ns;
+  sa.mean = nullptr; sa.partial = w.stat_partial; sa.C = C; sa.nslab = w.nslab;
+  hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.mean, C, w.nslab, (float)Nc, (float)Ns);
+  if (with_var) {
+    sa.mean = w.mean;
+    hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.var, C, w.nslab, (float)Nc, (float)Ns);
+  }
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
+               half_t* out16, float* out32, void* workspace, size_t workspace_bytes, int* sweeps_dev,
+               int stages, hipStream_t s) {
+  ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && Nc >= 2 && Ns >= 2 && P >= 1 && P <= 32);
+  ARG_CHECK(mode == WCT_MODE_NP || mode == WCT_MODE_TF);
+  WctCarve w = carve(workspace, C, Nc, Ns, P);
+  ARG_CHECK(workspace_bytes >= w.total);
+  int rc;
+  const size_t cc = (size_t)C * C;
+  if (stages & WCT_STAGE_COV) {
+  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, false, s))) return rc;
+
+  // covariance partials: matrix 2p+side, side 0 = content, 1 = style
+  for (int b = 0; b < 2; ++b) {
+    GemmArgs g = {};
+    const float* x = b == 0 ? content : style;
+    const int N = b == 0 ? Nc : Ns;
+    g.A = x; g.lda = C; g.a_kmajor = 1; g.B = x; g.ldb = C; g.b_kmajor = 1;
+    g.sA = g.sB = (size_t)N * C;
+    g.a_sub_m = w.mean + b * C; g.b_sub_n = w.mean + b * C; g.s_sub_m = g.s_sub_n = 2 * (size_t)C;
+    g.M = C; g.N = C; g.K = N; g.ksplit = w.ksplit;
+    g.out32 = w.cov_partial + (size_t)b * w.nsplit * cc; g.ldo = C; g.out_split_stride = cc;
+    g.s_out = 2 * (size_t)w.nsplit * cc;
+    // slices past this side's K write zeros (kbeg >= kend leaves acc = 0), keeping the reduction uniform
+    if ((rc = launch_gemm(g, w.nsplit, P, s))) return rc;
+  }
+  // eps_in < 0 selects the reference defaults: 1e-8 on the covariance diagonal for wct_tf
+  // (ops.py:24,45,50), 1e-5 inside the spectral gains for wct_np (ops.py:92,114,127)
+  const float eps_user = eps_in >= 0.f ? eps_in : (mode == WCT_MODE_TF ? 1e-8f : 1e-5f);
+  const float eps = mode == WCT_MODE_TF ? eps_user : 0.f;
+  hipLaunchKernelGGL(cov_finish_kernel, dim3((unsigned)((cc + 255) / 256), 2 * P), dim3(256), 0, s,
+                     w.cov_partial, w.A, C, w.nsplit, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps);
+  }
+  if (stages & WCT_STAGE_EIG) {
+    if ((rc = launch_jacobi_eigh(w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, s))) return rc;
+  }
+  if (!(stages & WCT_STAGE_APPLY)) return WCT_OK;
+
+  hipLaunchKernelGGL(spectral_gain_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.A, w.d, C, mode, eps_in >= 0.f ? eps_in : 1e-5f);
+  for (int b = 0; b < 2; ++b) {   // Tw = (Vc diag dc) Vc^T ; Tcs = (Vs diag ds) Vs^T
+    GemmArgs g = {};
+    g.A = w.V + b * cc; g.lda = C; g.a_kmajor = 0; g.a_scale_k = w.d + b * C; g.s_scale_k = 2 * (size_t)C;
+    g.B = w.V + b * cc; g.ldb = C; g.b_kmajor = 0; g.sA = g.sB = 2 * cc;
+    g.M = C; g.N = C; g.K = C; g.ksplit = C;
+    g.out32 = b == 0 ? w.Tw : w.Tcs; g.ldo = C; g.s_out = cc;
+    if ((rc = launch_gemm(g, 1, P, s))) return rc;
+  }
+  {
+    GemmArgs g = {};   // T = Tcs . Tw
+    g.A = w.Tcs; g.lda = C; g.a_kmajor = 0; g.B = w.Tw; g.ldb = C; g.b_kmajor = 1; g.sA = g.sB = cc;
+    g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = w.T; g.ldo = C; g.s_out = cc;
+    if ((rc = launch_gemm(g, 1, P, s))) return rc;
+  }
+  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)((cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, C, alpha, mode);
+  {  // out[n][j] = sum_k (x[n][k]-mc[k]) M[j][k] + bias[j]
+    GemmArgs g = {};
+    g.A = content; g.lda = C; g.a_kmajor = 0; g.sA = (size_t)Nc * C;
+    g.a_sub_k = w.mean; g.s_sub_k = 2 * (size_t)C;
+    g.B = w.M; g.ldb = C; g.b_kmajor = 0; g.sB = cc;
+    g.M = Nc; g.N = C; g.K = C; g.ksplit = C;
+    g.out32 = out32; g.out16 = out16; g.ldo = C; g.s_out = (size_t)Nc * C;
+    g.bias_n = w.bias; g.s_bias = C;
+    if ((rc = launch_gemm(g, 1, P, s))) return rc;
+  }
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// AdaIN (ops.py:282-294): out = alpha*((x-mu_c)*rsqrt(var_c+eps)*sqrt(var_s)+mu_s) + (1-alpha)*x
+// ---------------------------------------------------------------------------
+__global__ void adain_apply_kernel(const float* x, size_t n4_per_pair, int C, const float* mean, const float* var,
+                                   float alpha, float eps, half_t* out16, float* out32) {
+  const int pair = blockIdx.y;
+  const int cq = C / 4;
+  const float* mp = mean + (size_t)pair * 2 * C;
+  const float* vp = var + (size_t)pair * 2 * C;
+  const size_t base = (size_t)pair * n4_per_pair;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4_per_pair; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + (base + i) * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float inv = 1.f / sqrtf(vp[c + j] + eps);
+      const float y = (v[j] - mp[c + j]) * inv * sqrtf(vp[C + c + j]) + mp[C + c + j];
+      o[j] = alpha * y + (1.f - alpha) * v[j];
+    }
+    if (out32) *reinterpret_cast<f32x4*>(out32 + (base + i) * 4) = o;
+    if (out16) {
+      half4 h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (half_t)o[j];
+      *reinterpret_cast<half4*>(out16 + (base + i) * 4) = h;
+    }
+  }
+}
+
+int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, float eps,
+                 half_t* out16, float* out32, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  ARG_CHECK(C % 4 == 0 && C <= 1024 && Nc >= 1 && Ns >= 1 && P >= 1 && P <= 32);
+  WctCarve w = carve(workspace, C < 32 ? 32 : C, Nc, Ns, P);
+  ARG_CHECK(workspace_bytes >= w.total);
+  int rc;
+  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, true, s))) return rc;
+  const size_t n4 = (size_t)Nc * C / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adain_apply_kernel, dim3((unsigned)blocks, P), dim3(256), 0, s, content, n4, C, w.mean, w.var, alpha, eps, out16, out32);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}

@@ -1,0 +1,92 @@
+"""WCT: the inference facade of wct.py:14-106 on the MI355X path.
+
+    WCT(checkpoints, relu_targets, vgg_path, device='/gpu:0', ss_patch_size=3, ss_stride=1)
+    WCT.predict(content, style, alpha=1, swap5=False, ss_alpha=1, adain=False) -> uint8 HxWx3
+
+`checkpoints` / `vgg_path`: the reference restores TF checkpoints and a .t7 file
+(wct.py:46-58, vgg_normalised.py:16).  Neither format's weights exist offline, so
+this class takes, per decoder, a path to a .npz written by
+`wct_tf_amd.weights.save_weights` (or a weights dict via `weights=`); a missing
+decoder raises like the reference does (wct.py:58).
+"""
+import os
+import re
+
+import numpy as np
+
+from .context import Context
+from .model import WCTModel
+from .weights import load_weights
+
+
+def _device_index(device):
+    if isinstance(device, int):
+        return device
+    m = re.search(r'(\d+)\s*$', str(device))        # '/gpu:0' -> 0
+    return int(m.group(1)) if m else 0
+
+
+class WCT(object):
+    '''Stylize images with the WCT model on one MI355X'''
+
+    def __init__(self, checkpoints, relu_targets, vgg_path, device='/gpu:0',
+                 ss_patch_size=3, ss_stride=1, weights=None, wct_mode='tf'):
+        self.ss_patch_size = ss_patch_size
+        self.ss_stride = ss_stride
+        self.relu_targets = list(relu_targets)
+        self.wct_mode = wct_mode
+        self.model = WCTModel(mode='test', relu_targets=relu_targets, vgg_path=vgg_path,
+                              ss_patch_size=ss_patch_size, ss_stride=ss_stride)
+        self.content_input = self.model.content_input
+        self.decoded_output = self.model.decoded_output
+        self.sess = Context(_device_index(device))
+
+        if weights is None:
+            weights = {'encoder': None, 'decoder': {}}
+            if vgg_path is not None:
+                if not os.path.exists(vgg_path):
+                    raise Exception('No VGG weights found at {}'.format(vgg_path))
+                weights['encoder'] = load_weights(vgg_path)['encoder']
+            for relu_target, checkpoint_dir in zip(relu_targets, checkpoints or []):
+                path = checkpoint_dir
+                if os.path.isdir(path):
+                    path = os.path.join(path, 'decoder_{}.npz'.format(relu_target))
+                if not os.path.exists(path):
+                    raise Exception('No checkpoint found for target {} in dir {}'.format(relu_target, checkpoint_dir))
+                dec = load_weights(path)['decoder']
+                if relu_target not in dec:
+                    raise Exception('No checkpoint found for target {} in dir {}'.format(relu_target, checkpoint_dir))
+                weights['decoder'][relu_target] = dec[relu_target]
+        if weights.get('encoder') is None:
+            raise Exception('No VGG weights given')
+        self.sess.set_encoder(weights['encoder'])
+        for relu_target in relu_targets:
+            if relu_target not in weights['decoder']:
+                raise Exception('No checkpoint found for target {}'.format(relu_target))
+            self.sess.set_decoder(relu_target, weights['decoder'][relu_target])
+
+    @staticmethod
+    def preprocess(image):
+        if len(image.shape) == 3:  # Add batch dimension
+            image = np.expand_dims(image, 0)
+        return image / 255.        # Range [0,1]
+
+    @staticmethod
+    def postprocess(image):
+        return np.uint8(np.clip(image, 0, 1) * 255)
+
+    def predict(self, content, style, alpha=1, swap5=False, ss_alpha=1, adain=False):
+        '''Stylize a single content/style pair; arrays in [0,255], returns uint8 HxWx3.
+           The /255 preprocess and the clip*255 postprocess run inside the library
+           (fused at the ends of the kernel chain).'''
+        if swap5:
+            # style-swap (ops.py:145-278) is SURVEY 8f "next", not on this path yet
+            raise NotImplementedError('swap5 (style-swap) is not built on the MI355X path')
+        content = np.asarray(content)
+        style = np.asarray(style)
+        if content.dtype != np.uint8:
+            content = np.uint8(np.clip(content, 0, 255))
+        if style.dtype != np.uint8:
+            style = np.uint8(np.clip(style, 0, 255))
+        return self.sess.stylize(content, style, self.relu_targets, alpha=alpha, adain=adain,
+                                 wct_mode=self.wct_mode)
