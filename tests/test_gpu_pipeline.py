@@ -83,15 +83,41 @@ def test_pipeline_two_levels_teacher_forced_and_end_to_end(ctx, weights):
     assert got.shape == want.shape and psnr(got, want) > 35
 
 
-def test_pipeline_five_levels_end_to_end(ctx, weights):
+def test_pipeline_five_levels_teacher_forced_and_fused_equals_stepwise(ctx, weights):
+    """Full relu5_1->relu1_1 chain.  End-to-end equality with the oracle is NOT a usable
+    criterion on random weights: the oracle itself moves by ~28 LSB (mean) when ONE bit of
+    ONE content pixel flips (tests/test_oracle.py::test_five_level_chain_is_chaotic_on_random_weights),
+    so each level is checked on the oracle's own inputs (teacher forcing), and the fused
+    wct_stylize call must equal the same GPU ops chained step by step, bit for bit."""
+    from wct_tf_amd import _lib
     c = synthetic_image(1000, 128, 128)
     s = synthetic_image(2000, 128, 128)
     for mode in ('tf', 'np'):
-        want = _teacher_forced(ctx, weights, c, s, RELU_TARGETS, 0.8, mode)
+        _teacher_forced(ctx, weights, c, s, RELU_TARGETS, 0.8, mode)
         got = ctx.stylize(c, s, RELU_TARGETS, alpha=0.8, wct_mode=mode)
-        d = np.abs(got.astype(int) - want.astype(int))
-        print('5-level %s: psnr %.1f dB, max LSB %d, mean LSB %.3f' % (mode, psnr(got, want), d.max(), d.mean()))
-        assert got.shape == want.shape and psnr(got, want) > 30
+        x = np.float32(c / 255.)
+        s01 = np.float32(s / 255.)
+        for i, relu in enumerate(RELU_TARGETS):
+            if i > 0:
+                x = np.clip(x, 0, 1)
+            fc, fs = ctx.encode(x, relu), ctx.encode(s01, relu)
+            ch = fc.shape[-1]
+            t = ctx.transform(fc.reshape(-1, ch), fs.reshape(-1, ch), 0.8,
+                              _lib.WCT_TF if mode == 'tf' else _lib.WCT_NP).reshape(fc.shape)
+            x = ctx.decode(t, relu)
+        step = np.uint8(np.clip(x, 0, 1) * 255)
+        assert np.array_equal(got, step), mode
+
+
+def test_pipeline_three_levels_end_to_end(ctx, weights):
+    targets = ['relu3_1', 'relu2_1', 'relu1_1']
+    c = synthetic_image(1000, 96, 96)
+    s = synthetic_image(2000, 96, 96)
+    want = oracle.stylize(c, s, weights, targets, alpha=0.8)
+    got = ctx.stylize(c, s, targets, alpha=0.8)
+    d = np.abs(got.astype(int) - want.astype(int))
+    print('3-level end-to-end: psnr %.1f dB, max LSB %d, mean LSB %.3f' % (psnr(got, want), d.max(), d.mean()))
+    assert psnr(got, want) > 30
 
 
 def test_pipeline_adain_and_odd_sizes(ctx, weights):

@@ -139,3 +139,19 @@ def test_stylize_pipeline_shapes_and_chaining():
     assert levels[0][0].shape == (16, 24, 128) and levels[0][1].shape == (20, 12, 128)
     out_adain = oracle.stylize(c, s, w, targets, alpha=0.8, adain=True)
     assert out_adain.shape == out.shape and not np.array_equal(out, out_adain)
+
+
+def test_five_level_chain_is_chaotic_on_random_weights():
+    """Conditioning of the end-to-end problem with random (untrained) weights: flipping one
+    bit of one content pixel moves the oracle's OWN 5-level output by many LSB.  This is why
+    the GPU pipeline tests teacher-force each level instead of comparing the final image."""
+    w = synthetic_weights(42)
+    c = synthetic_image(1000, 64, 64)
+    s = synthetic_image(2000, 64, 64)
+    targets = ['relu5_1', 'relu4_1', 'relu3_1', 'relu2_1', 'relu1_1']
+    a = oracle.stylize(c, s, w, targets, alpha=0.8)
+    c2 = c.copy()
+    c2[32, 32, 0] ^= 1
+    b = oracle.stylize(c2, s, w, targets, alpha=0.8)
+    d = np.abs(a.astype(int) - b.astype(int))
+    assert d.mean() > 2.0, d.mean()

@@ -1,0 +1,43 @@
+"""Multi-GPU layer of the stylize path: one process per GPU, independent content/style pairs
+sharded statically, ONE exchange step -- a gather of the finished uint8 frames to rank 0
+(RCCL over xGMI when the tensors live on GPUs, gloo on CPU in the tests).
+
+The reference has no multi-device code at all (single device string, wct.py:17,31); units
+are the (content, style) pairs it already processes one at a time (stylize.py:70-100)."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, world_size, rank):
+    """Contiguous static shard [lo, hi) of `n_items` pairs for `rank`; sizes differ by at
+    most one and cover every item exactly once."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError('bad rank/world_size')
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def gather_frames(local_frames, world_size, rank, dst=0):
+    """Gather every rank's [b, H, W, 3] uint8 frames on `dst`; returns the [sum b, H, W, 3]
+    tensor there (rank order == global pair order of shard_range) and None elsewhere.
+    Equal shard sizes use one dist.gather; ragged shards pad to the largest."""
+    if world_size == 1:
+        return local_frames
+    b = torch.tensor([local_frames.shape[0]], dtype=torch.int64, device=local_frames.device)
+    sizes = [torch.zeros_like(b) for _ in range(world_size)]
+    dist.all_gather(sizes, b)
+    sizes = [int(s.item()) for s in sizes]
+    bmax = max(sizes)
+    send = local_frames
+    if send.shape[0] != bmax:
+        pad = torch.zeros((bmax - send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        send = torch.cat([send, pad], 0)
+    send = send.contiguous()
+    if rank == dst:
+        parts = [torch.empty_like(send) for _ in range(world_size)]
+        dist.gather(send, gather_list=parts, dst=dst)
+        return torch.cat([p[:n] for p, n in zip(parts, sizes)], 0)
+    dist.gather(send, gather_list=None, dst=dst)
+    return None
