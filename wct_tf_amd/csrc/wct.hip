@@ -10,6 +10,7 @@
 //   K7  apply         out = (x - mc) M^T + b,  M = alpha T + (1-alpha) I  (one GEMM,
 //                     blend and re-centring folded into M and b)
 #include "common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------
 // K3: per-channel sums over the pixel axis
@@ -236,11 +237,11 @@ __global__ void cov_finish_kernel(const float* partial, float* cov, int C, int n
 
 // ---------------------------------------------------------------------------
 // K5: batched symmetric eigensolver -- two-sided block Jacobi.
-//   blocks of 16 columns, round-robin over block pairs; each pair's 32x32
-//   diagonal problem gets one cyclic Jacobi sweep in LDS (jacobi_diag_kernel),
-//   then every 32x32 tile of A (and of the eigenvector matrix V) is updated as
-//   Qg^T A_gh Qh on fp32 MFMA (jacobi_update_kernel).  Two launches per step,
-//   C/16-1 steps per sweep.  A per-matrix `done` flag turns later launches into no-ops.
+//   Column blocks of B = M2/2 are paired round-robin; each pair's M2 x M2 diagonal
+//   problem gets one cyclic Jacobi sweep in LDS (jacobi_diag_kernel), then every
+//   M2 x M2 tile of A (and of the eigenvector matrix V) is updated as Qg^T A_gh Qh on
+//   fp32 MFMA (jacobi_update_kernel).  Two launches per step, C/B-1 steps per sweep.
+//   A per-matrix `done` flag turns later launches into no-ops.
 // ---------------------------------------------------------------------------
 struct JacobiState {
   unsigned int offmax;   // max |a_pq|/sqrt(a_pp a_qq) seen this sweep (float bits)
@@ -251,137 +252,220 @@ struct JacobiState {
 
 __device__ __forceinline__ int rr_idx(int pos, int step, int n) {
   // circle method: position 0 is fixed, the other n-1 rotate
-  return pos == 0 ? 0 : ((pos - 1 + step) % (n - 1)) + 1;
+  if (pos == 0) return 0;
+  int v = pos - 1 + step;
+  if (v >= n - 1) v -= n - 1;
+  return v + 1;
 }
 
+// blocks (bi, bj) of pair g at outer step `step`; step < 0 is the intra step: neighbours (2g, 2g+1)
+__device__ __forceinline__ void block_pair(int g, int step, int nblk, int& bi, int& bj) {
+  if (step < 0) { bi = 2 * g; bj = 2 * g + 1; }
+  else { bi = rr_idx(g, step, nblk); bj = rr_idx(nblk - 1 - g, step, nblk); }
+}
+
+template <int B>
 __device__ __forceinline__ int pair_index(int r, int bi, int bj) {
-  return r < 16 ? bi * 16 + r : bj * 16 + (r - 16);
+  return r < B ? bi * B + r : bj * B + (r - B);
 }
 
 constexpr float JACOBI_ROT_TOL = 1e-6f;    // skip rotations below this relative size
-constexpr float JACOBI_CONV_TOL = 3e-5f;   // a sweep that never saw more than this is the last one
+constexpr float JACOBI_CONV_TOL = 2e-3f;   // a sweep that never saw more than this is the last one (quadratic convergence)
 constexpr float JACOBI_FLOOR = 1e-6f;      // both diagonals below this: the pair cannot reach the 1e-5 cut-off
 
-__global__ __launch_bounds__(256) void jacobi_diag_kernel(float* A, float* Qbuf, JacobiState* st, int C, int step) {
+// rotation (c, s) that annihilates a_pq; `off` = pre-rotation relative size (0 if skipped).
+// t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (a_qq - a_pp) / (2 a_pq), written as
+// t = +-|a_pq| / (|tau| + sqrt(tau^2 + a_pq^2)), tau = (a_qq - a_pp)/2: three transcendentals
+// on the dependent chain (sqrt, rcp, rsq) and no division by a_pq.
+__device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq, float& c, float& s, float& off) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  // (a) both diagonals far below the 1e-5 cut-off: whatever they mix stays dropped;
+  // (b) coupling of a kept direction into a noise-level one with a negligible angle
+  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) && !(small < JACOBI_FLOOR && aapq < 1e-6f * big);
+  const bool rot = live && (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) && (aapq > 1e-36f);
+  const float rel = den2 > 0.f ? fminf(aapq * __builtin_amdgcn_rsqf(den2), 1.f) : 1.f;
+  const float tau = 0.5f * (aqq - app);
+  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
+  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
+  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
+  const float n2 = 1.f + t * t;
+  float r = __builtin_amdgcn_rsqf(n2);
+  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
+  c = rot ? r : 1.f;
+  s = rot ? r * t : 0.f;
+  off = rot ? rel : 0.f;
+}
+
+// Rotation sets on an N x N symmetric pair problem (N = 32 or 64: blocks I = 0..N/2-1 and
+// J = N/2..N-1) held in LDS, by (N/2)^2 threads t = (k, l), N/2 disjoint pairs per set.
+// S and the accumulated rotations Q are interleaved as float2 {S[r][c], Q[r][c]} so thread
+// (k, l) moves its 2x2 block of both with four 8-byte LDS reads and writes (rows {p_k, q_k} x
+// columns {p_l, q_l}).  Two LDS images ping-pong, so a rotation set costs ONE barrier.  Each
+// thread derives rotation(l) from three more reads; rotation(k) is fetched from the lane of
+// its own wave that has l == k (ds_bpermute: no LDS round trip, no serial section).
+//   SWEEP_CROSS  the (N/2)^2 pairs (i in I, j in J), N/2 sets     -- one outer step
+//   SWEEP_INTRA  the pairs inside I and inside J, N/2-1 sets      -- once per outer sweep
+// so that one outer sweep visits every pair of the C indices exactly once (a true cyclic
+// Jacobi sweep).  All threads of the block call this together (contains __syncthreads()).
+// Returns the index of the image that holds the result.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+enum { SWEEP_CROSS = 1, SWEEP_INTRA = 2 };
+template <int MODE, int N>
+__device__ __forceinline__ void sweep_pair(int j, int s, int& p, int& q) {
+  constexpr int NP = N / 2;
+  if (MODE == SWEEP_CROSS) { p = j; q = NP + ((j + s) & (NP - 1)); }
+  else { const int base = j & (NP / 2) ? NP : 0, jj = j & (NP / 2 - 1); p = base + rr_idx(jj, s, NP); q = base + rr_idx(NP - 1 - jj, s, NP); }
+}
+template <int MODE, int N>
+__device__ __forceinline__ int jacobi_sets(f32x2* SQ, int t, float& my_off) {
+  constexpr int NP = N / 2, PITCH = N + 1, IMG = N * PITCH;
+  constexpr int NSETS = MODE == SWEEP_CROSS ? NP : NP - 1;
+  const int k = t / NP, l = t % NP;
+  const int src_lane = (t & (64 - NP)) | k;      // lane of my wave whose l equals my k
+  int cur = 0;
+  for (int s = 0; s < NSETS; ++s) {
+    int pk, qk, pl, ql;
+    sweep_pair<MODE, N>(k, s, pk, qk);
+    sweep_pair<MODE, N>(l, s, pl, ql);
+    const f32x2* C0 = SQ + cur * IMG;
+    f32x2* N0 = SQ + (cur ^ 1) * IMG;
+    // every LDS read of the set is issued before anything depends on it
+    const float lpp = C0[pl * PITCH + pl][0], lqq = C0[ql * PITCH + ql][0], lpq = C0[pl * PITCH + ql][0];
+    const f32x2 app = C0[pk * PITCH + pl], apq = C0[pk * PITCH + ql];
+    const f32x2 aqp = C0[qk * PITCH + pl], aqq = C0[qk * PITCH + ql];
+    float cl, sl, offl;
+    jacobi_rotation(lpp, lqq, lpq, cl, sl, offl);
+    const float ck = __shfl(cl, src_lane, 64), sk = __shfl(sl, src_lane, 64);
+    my_off = fmaxf(my_off, offl);
+    // S: columns (pair l), then rows (pair k);  Q: columns only
+    const float ypp = cl * app[0] - sl * apq[0], ypq = sl * app[0] + cl * apq[0];
+    const float yqp = cl * aqp[0] - sl * aqq[0], yqq = sl * aqp[0] + cl * aqq[0];
+    f32x2 npp, npq, nqp, nqq;
+    npp[0] = ck * ypp - sk * yqp;  npq[0] = ck * ypq - sk * yqq;
+    nqp[0] = sk * ypp + ck * yqp;  nqq[0] = sk * ypq + ck * yqq;
+    npp[1] = cl * app[1] - sl * apq[1];  npq[1] = sl * app[1] + cl * apq[1];
+    nqp[1] = cl * aqp[1] - sl * aqq[1];  nqq[1] = sl * aqp[1] + cl * aqq[1];
+    N0[pk * PITCH + pl] = npp;  N0[pk * PITCH + ql] = npq;
+    N0[qk * PITCH + pl] = nqp;  N0[qk * PITCH + ql] = nqq;
+    cur ^= 1;
+    __syncthreads();
+  }
+  return cur;
+}
+
+// One outer step: pair problem of blocks (bi, bj) -> rotation matrix Q (M2 x M2) in Qbuf.
+template <int M2>
+__global__ __launch_bounds__((M2 / 2) * (M2 / 2)) void jacobi_diag_kernel(float* A, float* Qbuf, JacobiState* st, int C, int step) {
+  constexpr int B = M2 / 2, PITCH = M2 + 1, NT = B * B;
   const int m = blockIdx.y, g = blockIdx.x;
   if (st[m].done) return;
-  __shared__ float S[32][33];
-  __shared__ float Q[32][33];
-  __shared__ float cs[16][2];
-  __shared__ int pq[16][2];
-  __shared__ float offs[16];
+  extern __shared__ __attribute__((aligned(16))) float jsm[];
+  f32x2* SQ = reinterpret_cast<f32x2*>(jsm);         // [2][M2][PITCH]
   const int tid = threadIdx.x;
-  const int nblk = C / 16, npair = nblk / 2;
-  const int bi = rr_idx(g, step, nblk), bj = rr_idx(nblk - 1 - g, step, nblk);
+  const int nblk = C / B, npair = nblk / 2;
+  int bi, bj;
+  block_pair(g, step, nblk, bi, bj);
   float* Am = A + (size_t)m * C * C;
-  for (int e = tid; e < 1024; e += 256) {
-    int r = e >> 5, c = e & 31;
-    S[r][c] = Am[(size_t)pair_index(r, bi, bj) * C + pair_index(c, bi, bj)];
-    Q[r][c] = r == c ? 1.f : 0.f;
+  for (int e = tid; e < M2 * M2; e += NT) {
+    const int r = e / M2, c = e % M2;
+    f32x2 v;
+    v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
+    v[1] = r == c ? 1.f : 0.f;
+    SQ[r * PITCH + c] = v;
   }
   float my_off = 0.f;
   __syncthreads();
-  for (int s = 0; s < 31; ++s) {
-    if (tid < 16) {
-      const int p = rr_idx(tid, s, 32), q = rr_idx(31 - tid, s, 32);
-      const float app = S[p][p], aqq = S[q][q], apq = S[p][q];
-      const float den = sqrtf(fabsf(app * aqq));
-      float c = 1.f, sn = 0.f;
-      const bool live = fabsf(app) + fabsf(aqq) > JACOBI_FLOOR;
-      if (live && fabsf(apq) > JACOBI_ROT_TOL * den && fabsf(apq) > 1e-36f) {
-        my_off = fmaxf(my_off, den > 0.f ? fabsf(apq) / den : 1.f);
-        const float zeta = (aqq - app) / (2.f * apq);
-        const float t = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-        c = 1.f / sqrtf(1.f + t * t);
-        sn = c * t;
-      }
-      cs[tid][0] = c; cs[tid][1] = sn;
-      pq[tid][0] = p; pq[tid][1] = q;
-    }
-    __syncthreads();
-    {
-      const int k = tid >> 4, l = tid & 15;
-      const int pk = pq[k][0], qk = pq[k][1], pl = pq[l][0], ql = pq[l][1];
-      const float ck = cs[k][0], sk = cs[k][1], cl = cs[l][0], sl = cs[l][1];
-      const float xpp = S[pk][pl], xpq = S[pk][ql], xqp = S[qk][pl], xqq = S[qk][ql];
-      // columns (pair l), then rows (pair k)
-      const float ypp = cl * xpp - sl * xpq, ypq = sl * xpp + cl * xpq;
-      const float yqp = cl * xqp - sl * xqq, yqq = sl * xqp + cl * xqq;
-      S[pk][pl] = ck * ypp - sk * yqp;
-      S[pk][ql] = ck * ypq - sk * yqq;
-      S[qk][pl] = sk * ypp + ck * yqp;
-      S[qk][ql] = sk * ypq + ck * yqq;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = k + 16 * i;
-        const float qp = Q[r][pl], qq = Q[r][ql];
-        Q[r][pl] = cl * qp - sl * qq;
-        Q[r][ql] = sl * qp + cl * qq;
-      }
-    }
-    __syncthreads();
-  }
-  float* Qo = Qbuf + ((size_t)m * npair + g) * 1024;
-  for (int e = tid; e < 1024; e += 256) Qo[e] = Q[e >> 5][e & 31];
-  if (tid < 16) offs[tid] = my_off;
-  __syncthreads();
-  if (tid == 0) {
-    float mx = 0.f;
-    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, offs[i]);
-    atomicMax(&st[m].offmax, __float_as_uint(mx));
-  }
+  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2>(SQ, tid, my_off) : jacobi_sets<SWEEP_CROSS, M2>(SQ, tid, my_off);
+  float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
+  for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
+  for (int o = 32; o > 0; o >>= 1) my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
+  if ((tid & 63) == 0) atomicMax(&st[m].offmax, __float_as_uint(my_off));
 }
 
-// grid (2*npair*npair, nmat), one wave per 32x32 tile.
-__global__ __launch_bounds__(64) void jacobi_update_kernel(float* A, float* V, const float* Qbuf, const JacobiState* st, int C, int step) {
+// acc (32x32 MFMA C/D layout) -> the 16 B operands of the next 32x32x2 MFMA chain, in
+// registers: rows kk, kk+1 sit in one half-wave and rows kk+4, kk+5 in the other, one
+// v_permlane32_swap per register pair puts row kk / kk+1 (and kk+4 / kk+5) into the
+// lower / upper half.  b[kk/2] is the operand of k-step kk.
+__device__ __forceinline__ void acc_to_b_operands(const f32x16& acc, float (&b)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = 4 * q + 2 * p;
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r]), __float_as_uint(acc[r + 1]), false, false);
+      b[(8 * q + 2 * p) / 2] = __uint_as_float(sw[0]);
+      b[(8 * q + 2 * p + 4) / 2] = __uint_as_float(sw[1]);
+    }
+}
+
+// One M2 x M2 tile per block: 64 threads (one wave) for M2 = 32, 256 threads (2x2 waves of
+// 32x32 quadrants) for M2 = 64.  grid (2*npair*npair, nmat): first the A tiles (g, h), then
+// the V tiles (row block g, column pair h).
+template <int M2>
+__global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(float* A, float* V, const float* Qbuf, const JacobiState* st, int C, int step) {
+  constexpr int B = M2 / 2, PITCH = M2 + 1;
   const int m = blockIdx.y;
   if (st[m].done) return;
-  __shared__ float Xs[32][33];
-  __shared__ float Qh[32][33];
-  __shared__ float Qg[32][33];
-  const int lane = threadIdx.x;
-  const int nblk = C / 16, npair = nblk / 2;
+  __shared__ float Xs[M2 * PITCH];
+  __shared__ float Qh[M2 * PITCH];
+  __shared__ float Qg[M2 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nthr = M2 == 32 ? 64 : 256;
+  const int nblk = C / B, npair = nblk / 2;
   int t = blockIdx.x;
   const bool is_v = t >= npair * npair;
   if (is_v) t -= npair * npair;
-  const int g = t / npair, h = t % npair;       // for V tiles g is the 32-row block index
-  const int hi = rr_idx(h, step, nblk), hj = rr_idx(nblk - 1 - h, step, nblk);
-  int gi = 0, gj = 0;
-  if (!is_v) { gi = rr_idx(g, step, nblk); gj = rr_idx(nblk - 1 - g, step, nblk); }
+  const int g = t / npair, h = t % npair;       // for V tiles g is the M2-row block index
+  int hi, hj, gi = 0, gj = 0;
+  block_pair(h, step, nblk, hi, hj);
+  if (!is_v) block_pair(g, step, nblk, gi, gj);
   float* X = (is_v ? V : A) + (size_t)m * C * C;
-  const float* Qhp = Qbuf + ((size_t)m * npair + h) * 1024;
-  const float* Qgp = Qbuf + ((size_t)m * npair + g) * 1024;
-  for (int e = lane; e < 1024; e += 64) {
-    const int r = e >> 5, c = e & 31;
-    const int gr = is_v ? g * 32 + r : pair_index(r, gi, gj);
-    Xs[r][c] = X[(size_t)gr * C + pair_index(c, hi, hj)];
-    Qh[r][c] = Qhp[e];
-    if (!is_v) Qg[r][c] = Qgp[e];
+  const float* Qhp = Qbuf + ((size_t)m * npair + h) * (M2 * M2);
+  const float* Qgp = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
+  for (int e = tid; e < M2 * M2; e += nthr) {
+    const int r = e / M2, c = e % M2;
+    const int gr = is_v ? g * M2 + r : pair_index<B>(r, gi, gj);
+    Xs[r * PITCH + c] = X[(size_t)gr * C + pair_index<B>(c, hi, hj)];
+    Qh[r * PITCH + c] = Qhp[e];
+    if (!is_v) Qg[r * PITCH + c] = Qgp[e];
   }
   __syncthreads();
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;     // quadrant origin (0,0 for M2 = 32)
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int li = lane & 31, lk = lane >> 5;
-#pragma unroll
-  for (int kk = 0; kk < 32; kk += 2)      // T = X . Qh
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[li][kk + lk], Qh[kk + lk][li], acc, 0, 0, 0);
+#pragma unroll 8
+  for (int kk = 0; kk < M2; kk += 2)      // T = X . Qh
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[(wi + li) * PITCH + kk + lk], Qh[(kk + lk) * PITCH + wj + li], acc, 0, 0, 0);
   if (!is_v) {
-    __syncthreads();
+    if (M2 == 32) {
+      float bop[16];
+      acc_to_b_operands(acc, bop);          // T stays in registers
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Xs[(r & 3) + 8 * (r >> 2) + 4 * lk][li] = acc[r];
-    __syncthreads();
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int kk = 0; kk < 32; kk += 2)  // Y = Qg^T . T
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qg[(kk + lk) * PITCH + li], bop[kk / 2], acc, 0, 0, 0);
+    } else {
+      __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2)    // Y = Qg^T . T
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qg[kk + lk][li], Xs[kk + lk][li], acc, 0, 0, 0);
+      for (int r = 0; r < 16; ++r) Xs[(wi + (r & 3) + 8 * (r >> 2) + 4 * lk) * PITCH + wj + li] = acc[r];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+      for (int kk = 0; kk < M2; kk += 2)  // Y = Qg^T . T
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qg[(kk + lk) * PITCH + wi + li], Xs[(kk + lk) * PITCH + wj + li], acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-    const int gr = is_v ? g * 32 + row : pair_index(row, gi, gj);
-    X[(size_t)gr * C + pair_index(li, hi, hj)] = acc[r];
+    const int row = wi + (r & 3) + 8 * (r >> 2) + 4 * lk;
+    const int gr = is_v ? g * M2 + row : pair_index<B>(row, gi, gj);
+    X[(size_t)gr * C + pair_index<B>(wj + li, hi, hj)] = acc[r];
   }
 }
 
@@ -408,7 +492,23 @@ __global__ void jacobi_export_sweeps_kernel(const JacobiState* st, int* out, int
 constexpr int JACOBI_MAX_SWEEPS = 12;
 
 size_t jacobi_workspace_bytes(int C, int nmat) {
-  return (size_t)nmat * (C / 32) * 1024 * sizeof(float) + 256 + (size_t)nmat * sizeof(JacobiState);
+  return (size_t)nmat * C * 64 * sizeof(float) + 256 + (size_t)nmat * sizeof(JacobiState);   // Q tiles: (C/M2) * M2*M2 <= C*64
+}
+
+template <int M2>
+static void jacobi_launch_sweeps(float* A, float* V, float* Qbuf, JacobiState* st, int C, int nmat, hipStream_t s) {
+  constexpr int B = M2 / 2;
+  const int nblk = C / B, npair = nblk / 2;
+  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2);
+  for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
+    // step -1 rotates the pairs inside each block, steps 0.. the cross pairs of every block pair:
+    // each pair of indices exactly once per sweep
+    for (int step = -1; step < nblk - 1; ++step) {
+      hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, nmat), dim3((M2 / 2) * (M2 / 2)), lds, s, A, Qbuf, st, C, step);
+      hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3(2 * npair * npair, nmat), dim3(M2 == 32 ? 64 : 256), 0, s, A, V, Qbuf, st, C, step);
+    }
+    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, s, st, nmat);
+  }
 }
 
 int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
@@ -416,17 +516,13 @@ int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, siz
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
   ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
   float* Qbuf = reinterpret_cast<float*>(workspace);
-  size_t qbytes = (size_t)nmat * (C / 32) * 1024 * sizeof(float);
+  size_t qbytes = (size_t)nmat * C * 64 * sizeof(float);
   JacobiState* st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
-  const int nblk = C / 16, npair = nblk / 2;
   hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, nmat), dim3(256), 0, s, V, st, C);
-  for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
-    for (int step = 0; step < nblk - 1; ++step) {
-      hipLaunchKernelGGL(jacobi_diag_kernel, dim3(npair, nmat), dim3(256), 0, s, A, Qbuf, st, C, step);
-      hipLaunchKernelGGL(jacobi_update_kernel, dim3(2 * npair * npair, nmat), dim3(64), 0, s, A, V, Qbuf, st, C, step);
-    }
-    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, s, st, nmat);
-  }
+  // block pairs of 64 indices (32-column blocks) by default; WCT_JACOBI_M2=32 selects 16-column blocks
+  static const int force32 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 32 : 0;
+  if (!force32 && C % 64 == 0) jacobi_launch_sweeps<64>(A, V, Qbuf, st, C, nmat, s);
+  else jacobi_launch_sweeps<32>(A, V, Qbuf, st, C, nmat, s);
   if (sweeps_done_dev) hipLaunchKernelGGL(jacobi_export_sweeps_kernel, dim3(1), dim3(64), 0, s, st, sweeps_done_dev, nmat);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
@@ -517,7 +613,7 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   w.T = (float*)take(P * cc);
   w.M = (float*)take(P * cc);
   w.bias = (float*)take((size_t)P * C * sizeof(float));
-  w.jacobi_bytes = jacobi_workspace_bytes(C, 2 * P);
+  w.jacobi_bytes = 2 * jacobi_workspace_bytes(C, P) + 1024;     // two independent halves (two streams)
   w.jacobi_ws = take(w.jacobi_bytes);
   w.total = off;
   return w;
@@ -545,7 +641,7 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
 
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
                half_t* out16, float* out32, void* workspace, size_t workspace_bytes, int* sweeps_dev,
-               int stages, hipStream_t s) {
+               int stages, hipStream_t s, hipStream_t s2, hipEvent_t ev_fork, hipEvent_t ev_join) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && Nc >= 2 && Ns >= 2 && P >= 1 && P <= 32);
   ARG_CHECK(mode == WCT_MODE_NP || mode == WCT_MODE_TF);
   WctCarve w = carve(workspace, C, Nc, Ns, P);
@@ -577,7 +673,22 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
                      w.cov_partial, w.A, C, w.nsplit, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps);
   }
   if (stages & WCT_STAGE_EIG) {
-    if ((rc = launch_jacobi_eigh(w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, s))) return rc;
+    if (s2 && P >= 2) {
+      // The eigensolver alternates a latency-bound kernel on a few workgroups (pair problems) with a
+      // chip-wide tile update.  Two halves of the batch on two streams let one half's pair problems
+      // hide under the other half's tile update.
+      const int n0 = P, n1 = 2 * P - n0;
+      const size_t b0 = (jacobi_workspace_bytes(C, n0) + 255) & ~(size_t)255;
+      HIP_TRY(hipEventRecord(ev_fork, s));
+      HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
+      if ((rc = launch_jacobi_eigh(w.A, w.V, C, n0, w.jacobi_ws, b0, sweeps_dev, s))) return rc;
+      if ((rc = launch_jacobi_eigh(w.A + (size_t)n0 * cc, w.V + (size_t)n0 * cc, C, n1, (char*)w.jacobi_ws + b0,
+                                   w.jacobi_bytes - b0, sweeps_dev ? sweeps_dev + n0 : nullptr, s2))) return rc;
+      HIP_TRY(hipEventRecord(ev_join, s2));
+      HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
+    } else {
+      if ((rc = launch_jacobi_eigh(w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, s))) return rc;
+    }
   }
   if (!(stages & WCT_STAGE_APPLY)) return WCT_OK;
 
