@@ -265,7 +265,11 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 // the layer is bound by its 64-channel output write)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int tiles_x) {
-  __shared__ float patch[18][18][3];
+  // 16x16 pixel tile x 64 channels per block.  Thread t owns channel chunk (t & 7) (8 channels)
+  // of the 8 pixels (t >> 3) + 32 i: the 8 lanes of a pixel write its 128 B (fp16) contiguously,
+  // so one store instruction covers 8 whole pixels.
+  __shared__ float patch[18 * 18 * 3];
+  __shared__ __attribute__((aligned(16))) float wl[27 * 64];
   const int tid = threadIdx.x;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int b = blockIdx.y;
@@ -277,42 +281,55 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int ti
     int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
     float v = xb[((size_t)iy * p.W + ix) * 3 + c];
     if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-    patch[py][px][c] = v;
+    patch[i] = v;
   }
+  for (int i = tid; i < 27 * 64 / 4; i += 256)
+    reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
   __syncthreads();
-  const int ly = tid >> 4, lx = tid & 15;
-  const int oy = y0 + ly, ox = x0 + lx;
-  float in[27];
+  const int chunk = tid & 7, pg = tid >> 3;
+  float acc[8][8];
+  {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + chunk * 8);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + chunk * 8 + 4);
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky)
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) in[(ky * 3 + kx) * 3 + c] = patch[ly + ky][lx + kx][c];
-  if (oy >= p.H || ox >= p.W) return;
-  const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-#pragma unroll 1
-  for (int cg = 0; cg < 8; ++cg) {       // 8 channels at a time keeps the accumulators in registers
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = p.bias[cg * 8 + j];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(in[k], p.w[k * 64 + cg * 8 + j], acc[j]);   // uniform address -> scalar loads
+      for (int j = 0; j < 4; ++j) { acc[i][j] = b0[j]; acc[i][4 + j] = b1[j]; }
     }
+  }
+#pragma unroll 3
+  for (int k = 0; k < 27; ++k) {
+    const int tap = k / 3, c = k - tap * 3;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + k * 64 + chunk * 8);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + k * 64 + chunk * 8 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    for (int i = 0; i < 8; ++i) {
+      const int pix = pg + 32 * i;
+      const float in = patch[(((pix >> 4) + ky) * 18 + (pix & 15) + kx) * 3 + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[i][j] = fmaf(in, w0[j], acc[i][j]); acc[i][4 + j] = fmaf(in, w1[j], acc[i][4 + j]); }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int pix = pg + 32 * i;
+    const int oy = y0 + (pix >> 4), ox = x0 + (pix & 15);
+    if (oy >= p.H || ox >= p.W) continue;
+    const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * 64 + chunk * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[i][j], 0.f);
     if (p.y16) {
       half8 h;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (half_t)acc[j];
-      *reinterpret_cast<half8*>(p.y16 + pix * 64 + cg * 8) = h;
+      for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
+      *reinterpret_cast<half8*>(p.y16 + o) = h;
     }
     if (p.y32) {
-      f32x4 v0 = {acc[0], acc[1], acc[2], acc[3]}, v1 = {acc[4], acc[5], acc[6], acc[7]};
-      *reinterpret_cast<f32x4*>(p.y32 + pix * 64 + cg * 8) = v0;
-      *reinterpret_cast<f32x4*>(p.y32 + pix * 64 + cg * 8 + 4) = v1;
+      f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(p.y32 + o) = v0;
+      *reinterpret_cast<f32x4*>(p.y32 + o + 4) = v1;
     }
   }
 }

@@ -495,37 +495,81 @@ size_t jacobi_workspace_bytes(int C, int nmat) {
   return (size_t)nmat * C * 64 * sizeof(float) + 256 + (size_t)nmat * sizeof(JacobiState);   // Q tiles: (C/M2) * M2*M2 <= C*64
 }
 
+// One group = a set of matrices on its own stream (the two halves of a batch run as two groups so
+// that one half's latency-bound pair problems hide under the other half's chip-wide tile update).
+struct JacobiGroup {
+  float* A; float* V; int nmat; float* Qbuf; JacobiState* st; hipStream_t stream; int* sweeps_out;
+};
+
+static JacobiState* jacobi_host_flags() {
+  static JacobiState* h = nullptr;            // pinned, 2 groups x 64 matrices
+  if (!h && hipHostMalloc((void**)&h, 2 * 64 * sizeof(JacobiState)) != hipSuccess) h = nullptr;
+  return h;
+}
+
 template <int M2>
-static void jacobi_launch_sweeps(float* A, float* V, float* Qbuf, JacobiState* st, int C, int nmat, hipStream_t s) {
+static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   constexpr int B = M2 / 2;
   const int nblk = C / B, npair = nblk / 2;
   const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2);
+  JacobiState* host = jacobi_host_flags();
+  for (int g = 0; g < ngrp; ++g)
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].V, grp[g].st, C);
   for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
     // step -1 rotates the pairs inside each block, steps 0.. the cross pairs of every block pair:
-    // each pair of indices exactly once per sweep
-    for (int step = -1; step < nblk - 1; ++step) {
-      hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, nmat), dim3((M2 / 2) * (M2 / 2)), lds, s, A, Qbuf, st, C, step);
-      hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3(2 * npair * npair, nmat), dim3(M2 == 32 ? 64 : 256), 0, s, A, V, Qbuf, st, C, step);
+    // each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
+    for (int step = -1; step < nblk - 1; ++step)
+      for (int g = 0; g < ngrp; ++g) {
+        const JacobiGroup& G = grp[g];
+        hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3((M2 / 2) * (M2 / 2)), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
+        hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3(2 * npair * npair, G.nmat), dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
+      }
+    for (int g = 0; g < ngrp; ++g)
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].nmat);
+    // From the 4th sweep on, read the convergence flags back and stop launching once every matrix is
+    // done (the `done` flag alone would turn the remaining launches into no-ops, at ~3 us apiece).
+    if (host && sweep >= 3 && sweep + 1 < JACOBI_MAX_SWEEPS) {
+      for (int g = 0; g < ngrp; ++g)
+        HIP_TRY(hipMemcpyAsync(host + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, grp[g].stream));
+      bool all = true;
+      for (int g = 0; g < ngrp; ++g) {
+        HIP_TRY(hipStreamSynchronize(grp[g].stream));
+        for (int m = 0; m < grp[g].nmat; ++m) all = all && host[g * 64 + m].done;
+      }
+      if (all) break;
     }
-    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, s, st, nmat);
   }
+  for (int g = 0; g < ngrp; ++g)
+    if (grp[g].sweeps_out)
+      hipLaunchKernelGGL(jacobi_export_sweeps_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
+                             int* sweeps_out, hipStream_t s) {
+  ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
+  ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
+  const size_t qbytes = (size_t)nmat * C * 64 * sizeof(float);
+  G->A = A; G->V = V; G->nmat = nmat; G->Qbuf = reinterpret_cast<float*>(workspace);
+  G->st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
+  G->stream = s; G->sweeps_out = sweeps_out;
+  return WCT_OK;
+}
+
+static int jacobi_dispatch(JacobiGroup* grp, int ngrp, int C) {
+  // block pairs of 64 indices (32-column blocks) by default; WCT_JACOBI_M2=32 selects 16-column blocks
+  static const int force32 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 32 : 0;
+  if (!force32 && C % 64 == 0) return jacobi_run_groups<64>(grp, ngrp, C);
+  return jacobi_run_groups<32>(grp, ngrp, C);
 }
 
 int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
                        int* sweeps_done_dev, hipStream_t s) {
-  ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
-  ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
-  float* Qbuf = reinterpret_cast<float*>(workspace);
-  size_t qbytes = (size_t)nmat * C * 64 * sizeof(float);
-  JacobiState* st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
-  hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, nmat), dim3(256), 0, s, V, st, C);
-  // block pairs of 64 indices (32-column blocks) by default; WCT_JACOBI_M2=32 selects 16-column blocks
-  static const int force32 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 32 : 0;
-  if (!force32 && C % 64 == 0) jacobi_launch_sweeps<64>(A, V, Qbuf, st, C, nmat, s);
-  else jacobi_launch_sweeps<32>(A, V, Qbuf, st, C, nmat, s);
-  if (sweeps_done_dev) hipLaunchKernelGGL(jacobi_export_sweeps_kernel, dim3(1), dim3(64), 0, s, st, sweeps_done_dev, nmat);
-  HIP_TRY(hipGetLastError());
-  return WCT_OK;
+  JacobiGroup G;
+  int rc = jacobi_make_group(&G, A, V, C, nmat, workspace, workspace_bytes, sweeps_done_dev, s);
+  if (rc) return rc;
+  return jacobi_dispatch(&G, 1, C);
 }
 
 // ---------------------------------------------------------------------------
@@ -681,9 +725,11 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       const size_t b0 = (jacobi_workspace_bytes(C, n0) + 255) & ~(size_t)255;
       HIP_TRY(hipEventRecord(ev_fork, s));
       HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
-      if ((rc = launch_jacobi_eigh(w.A, w.V, C, n0, w.jacobi_ws, b0, sweeps_dev, s))) return rc;
-      if ((rc = launch_jacobi_eigh(w.A + (size_t)n0 * cc, w.V + (size_t)n0 * cc, C, n1, (char*)w.jacobi_ws + b0,
-                                   w.jacobi_bytes - b0, sweeps_dev ? sweeps_dev + n0 : nullptr, s2))) return rc;
+      JacobiGroup grp[2];
+      if ((rc = jacobi_make_group(&grp[0], w.A, w.V, C, n0, w.jacobi_ws, b0, sweeps_dev, s))) return rc;
+      if ((rc = jacobi_make_group(&grp[1], w.A + (size_t)n0 * cc, w.V + (size_t)n0 * cc, C, n1, (char*)w.jacobi_ws + b0,
+                                  w.jacobi_bytes - b0, sweeps_dev ? sweeps_dev + n0 : nullptr, s2))) return rc;
+      if ((rc = jacobi_dispatch(grp, 2, C))) return rc;
       HIP_TRY(hipEventRecord(ev_join, s2));
       HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
     } else {
