@@ -7,6 +7,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <vector>
 
 // ---------------------------------------------------------------------------
@@ -50,8 +51,9 @@ struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
 struct wct_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;     // second stream: half of each level's eigenproblems
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra streams: each level's eigenproblems run in up to 4 groups
+  int nside = 3;
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   bool enc_loaded = false;
   float* first_w = nullptr;        // folded conv1_1 [27][64]
   float* first_b = nullptr;
@@ -127,13 +129,16 @@ extern "C" int wct_create(int device, wct_ctx** out) {
     delete c;
     return WCT_ERR_HIP;
   }
-  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+  bool ok = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 3 && ok; ++i)
+    ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
     wct_set_error("hipStreamCreate/hipEventCreate failed");
     delete c;
     return WCT_ERR_HIP;
   }
+  if (const char* e = getenv("WCT_EIG_GROUPS")) { int n = atoi(e); c->nside = n < 1 ? 0 : (n > 4 ? 3 : n - 1); }
   *out = c;
   return WCT_OK;
 }
@@ -164,9 +169,8 @@ extern "C" void wct_destroy(wct_ctx* c) {
   for (auto& b : c->feat_s) if (b.p) hipFree(b.p);
   for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto& e : c->free_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  hipStreamSynchronize(c->stream2);
-  hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join);
-  hipStreamDestroy(c->stream2);
+  hipEventDestroy(c->ev_fork);
+  for (int i = 0; i < 3; ++i) { hipStreamSynchronize(c->side[i]); hipEventDestroy(c->ev_join[i]); hipStreamDestroy(c->side[i]); }
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -446,14 +450,14 @@ static int run_transform(wct_ctx* c, const float* fc, int Nc, const float* fs, i
   const int mode = (flags & WCT_FLAG_MODE_NP) ? WCT_MODE_NP : WCT_MODE_TF;
   {
     ProfScope ps(c, 4, (double)P * 2.0 * C * C * ((double)Nc + Ns), (double)P * 2.0 * ((double)Nc + Ns) * C * 4);
-    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, nullptr, nullptr));
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, 0, nullptr, nullptr));
   }
   {
     ProfScope ps(c, 5, 0, 0);
-    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_EIG, c->stream, c->stream2, c->ev_fork, c->ev_join));
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_EIG, c->stream, c->side, c->nside, c->ev_fork, c->ev_join));
   }
   ProfScope ps(c, 6, (double)P * (2.0 * C * C * Nc + 6.0 * C * C * C), (double)P * Nc * C * (4 + (out16 ? 2 : 0) + (out32 ? 4 : 0)));
-  return launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_APPLY, c->stream, nullptr, nullptr, nullptr);
+  return launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_APPLY, c->stream, nullptr, 0, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------

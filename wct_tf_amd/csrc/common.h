@@ -88,8 +88,8 @@ size_t wct_workspace_bytes(int C, int Nc, int Ns, int P);
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P,
                float alpha, int mode, float eps /* <0: reference default */, half_t* out16, float* out32,
                void* workspace, size_t workspace_bytes, int* sweeps_dev, int stages, hipStream_t s,
-               hipStream_t s2 /* optional second stream for half of the eigenproblems */,
-               hipEvent_t ev_fork, hipEvent_t ev_join);
+               const hipStream_t* side /* optional extra streams: the eigenproblems are split over 1+nside */,
+               int nside, hipEvent_t ev_fork, const hipEvent_t* ev_join);
 enum { WCT_STAGE_COV = 1, WCT_STAGE_EIG = 2, WCT_STAGE_APPLY = 4, WCT_STAGE_ALL = 7 };
 int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P,
                  float alpha, float eps, half_t* out16, float* out32,

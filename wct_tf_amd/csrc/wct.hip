@@ -11,6 +11,8 @@
 //                     blend and re-centring folded into M and b)
 #include "common.h"
 #include <stdlib.h>
+#include <map>
+#include <string>
 
 // ---------------------------------------------------------------------------
 // K3: per-channel sums over the pixel axis
@@ -424,12 +426,29 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
   float* X = (is_v ? V : A) + (size_t)m * C * C;
   const float* Qhp = Qbuf + ((size_t)m * npair + h) * (M2 * M2);
   const float* Qgp = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
-  for (int e = tid; e < M2 * M2; e += nthr) {
+  // 16-byte global loads, all issued before the first LDS write (the column index runs inside one
+  // 16-float / 32-float block, so a float4 never straddles the two blocks of a pair)
+  constexpr int NV = M2 * M2 / 4 / (M2 == 32 ? 64 : 256);       // float4 per thread per matrix
+  f32x4 xv[NV], hv[NV], gv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = (tid + i * nthr) * 4;
     const int r = e / M2, c = e % M2;
     const int gr = is_v ? g * M2 + r : pair_index<B>(r, gi, gj);
-    Xs[r * PITCH + c] = X[(size_t)gr * C + pair_index<B>(c, hi, hj)];
-    Qh[r * PITCH + c] = Qhp[e];
-    if (!is_v) Qg[r * PITCH + c] = Qgp[e];
+    xv[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * C + pair_index<B>(c, hi, hj));
+    hv[i] = *reinterpret_cast<const f32x4*>(Qhp + e);
+    if (!is_v) gv[i] = *reinterpret_cast<const f32x4*>(Qgp + e);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = (tid + i * nthr) * 4;
+    const int r = e / M2, c = e % M2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Xs[r * PITCH + c + j] = xv[i][j];
+      Qh[r * PITCH + c + j] = hv[i][j];
+      if (!is_v) Qg[r * PITCH + c + j] = gv[i][j];
+    }
   }
   __syncthreads();
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;     // quadrant origin (0,0 for M2 = 32)
@@ -502,38 +521,97 @@ struct JacobiGroup {
 };
 
 static JacobiState* jacobi_host_flags() {
-  static JacobiState* h = nullptr;            // pinned, 2 groups x 64 matrices
-  if (!h && hipHostMalloc((void**)&h, 2 * 64 * sizeof(JacobiState)) != hipSuccess) h = nullptr;
+  static JacobiState* h = nullptr;            // pinned, 4 groups x 64 matrices
+  if (!h && hipHostMalloc((void**)&h, 4 * 64 * sizeof(JacobiState)) != hipSuccess) h = nullptr;
   return h;
+}
+
+// One sweep = (C/B + 1) x 2 kernels per group; at ~4-5 us of host time per launch several groups
+// would be launch-bound, so a sweep is captured once into a hipGraph (cross-stream capture: the side
+// streams fork from and join back to the first group's stream) and replayed once per sweep.
+struct SweepGraph { hipGraphExec_t exec; };
+static std::map<std::string, SweepGraph>& sweep_graph_cache() {
+  static std::map<std::string, SweepGraph> c;
+  return c;
+}
+
+template <int M2>
+static void jacobi_enqueue_sweep(const JacobiGroup* grp, int ngrp, int C) {
+  constexpr int B = M2 / 2;
+  const int nblk = C / B, npair = nblk / 2;
+  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2);
+  // step -1 rotates the pairs inside each block, steps 0.. the cross pairs of every block pair:
+  // each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
+  for (int step = -1; step < nblk - 1; ++step)
+    for (int g = 0; g < ngrp; ++g) {
+      const JacobiGroup& G = grp[g];
+      hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3((M2 / 2) * (M2 / 2)), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
+      hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3(2 * npair * npair, G.nmat), dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
+    }
+  for (int g = 0; g < ngrp; ++g)
+    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].nmat);
+}
+
+template <int M2>
+static int jacobi_sweep_graph(const JacobiGroup* grp, int ngrp, int C, hipGraphExec_t* out) {
+  std::string key((const char*)grp, sizeof(JacobiGroup) * ngrp);
+  key.append((const char*)&C, sizeof(C));
+  const int m2 = M2;
+  key.append((const char*)&m2, sizeof(m2));
+  auto& cache = sweep_graph_cache();
+  auto it = cache.find(key);
+  if (it != cache.end()) { *out = it->second.exec; return WCT_OK; }
+  hipStream_t main = grp[0].stream;
+  hipEvent_t fork, join[4];
+  HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  for (int g = 1; g < ngrp; ++g) HIP_TRY(hipEventCreateWithFlags(&join[g], hipEventDisableTiming));
+  HIP_TRY(hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal));
+  HIP_TRY(hipEventRecord(fork, main));
+  for (int g = 1; g < ngrp; ++g) HIP_TRY(hipStreamWaitEvent(grp[g].stream, fork, 0));
+  jacobi_enqueue_sweep<M2>(grp, ngrp, C);
+  for (int g = 1; g < ngrp; ++g) {
+    HIP_TRY(hipEventRecord(join[g], grp[g].stream));
+    HIP_TRY(hipStreamWaitEvent(main, join[g], 0));
+  }
+  hipGraph_t graph;
+  HIP_TRY(hipStreamEndCapture(main, &graph));
+  SweepGraph sg;
+  HIP_TRY(hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0));
+  HIP_TRY(hipGraphDestroy(graph));
+  cache[key] = sg;
+  *out = sg.exec;
+  return WCT_OK;
 }
 
 template <int M2>
 static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
-  constexpr int B = M2 / 2;
-  const int nblk = C / B, npair = nblk / 2;
-  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2);
+  // measured on MI355X (ROCm 7.2): replaying the captured multi-stream sweep is SLOWER than eager launches
+  // (4 groups: 29.0 vs 22.4 ms/step), so the graph path is opt-in (WCT_JACOBI_GRAPH=1)
+  static const int use_graph = getenv("WCT_JACOBI_GRAPH") ? atoi(getenv("WCT_JACOBI_GRAPH")) : 0;
   JacobiState* host = jacobi_host_flags();
+  hipStream_t main = grp[0].stream;
   for (int g = 0; g < ngrp; ++g)
     hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].V, grp[g].st, C);
+  hipGraphExec_t exec = nullptr;
+  if (use_graph) {
+    // the graph forks from / joins to the main stream: the side streams' init kernels must be ordered first
+    for (int g = 1; g < ngrp; ++g) HIP_TRY(hipStreamSynchronize(grp[g].stream));
+    int rc = jacobi_sweep_graph<M2>(grp, ngrp, C, &exec);
+    if (rc) return rc;
+  }
   for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
-    // step -1 rotates the pairs inside each block, steps 0.. the cross pairs of every block pair:
-    // each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
-    for (int step = -1; step < nblk - 1; ++step)
-      for (int g = 0; g < ngrp; ++g) {
-        const JacobiGroup& G = grp[g];
-        hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3((M2 / 2) * (M2 / 2)), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
-        hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3(2 * npair * npair, G.nmat), dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
-      }
-    for (int g = 0; g < ngrp; ++g)
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].nmat);
+    if (exec) HIP_TRY(hipGraphLaunch(exec, main));
+    else jacobi_enqueue_sweep<M2>(grp, ngrp, C);
     // From the 4th sweep on, read the convergence flags back and stop launching once every matrix is
     // done (the `done` flag alone would turn the remaining launches into no-ops, at ~3 us apiece).
     if (host && sweep >= 3 && sweep + 1 < JACOBI_MAX_SWEEPS) {
-      for (int g = 0; g < ngrp; ++g)
-        HIP_TRY(hipMemcpyAsync(host + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, grp[g].stream));
       bool all = true;
       for (int g = 0; g < ngrp; ++g) {
-        HIP_TRY(hipStreamSynchronize(grp[g].stream));
+        hipStream_t sg = exec ? main : grp[g].stream;
+        HIP_TRY(hipMemcpyAsync(host + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, sg));
+      }
+      for (int g = 0; g < ngrp; ++g) {
+        HIP_TRY(hipStreamSynchronize(exec ? main : grp[g].stream));
         for (int m = 0; m < grp[g].nmat; ++m) all = all && host[g * 64 + m].done;
       }
       if (all) break;
@@ -541,7 +619,7 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   }
   for (int g = 0; g < ngrp; ++g)
     if (grp[g].sweeps_out)
-      hipLaunchKernelGGL(jacobi_export_sweeps_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat);
+      hipLaunchKernelGGL(jacobi_export_sweeps_kernel, dim3(1), dim3(64), 0, exec ? main : grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
@@ -560,7 +638,9 @@ static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat
 static int jacobi_dispatch(JacobiGroup* grp, int ngrp, int C) {
   // block pairs of 64 indices (32-column blocks) by default; WCT_JACOBI_M2=32 selects 16-column blocks
   static const int force32 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 32 : 0;
-  if (!force32 && C % 64 == 0) return jacobi_run_groups<64>(grp, ngrp, C);
+  static const int force64 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 64 : 0;
+  // measured (16 matrices): 64-wide pairs win from C = 256 up (half the tile traffic), 32-wide below
+  if (!force32 && C % 64 == 0 && (C >= 256 || force64)) return jacobi_run_groups<64>(grp, ngrp, C);
   return jacobi_run_groups<32>(grp, ngrp, C);
 }
 
@@ -657,7 +737,7 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   w.T = (float*)take(P * cc);
   w.M = (float*)take(P * cc);
   w.bias = (float*)take((size_t)P * C * sizeof(float));
-  w.jacobi_bytes = 2 * jacobi_workspace_bytes(C, P) + 1024;     // two independent halves (two streams)
+  w.jacobi_bytes = jacobi_workspace_bytes(C, 2 * P) + 4 * (1024 + 64 * sizeof(JacobiState));   // up to 4 groups
   w.jacobi_ws = take(w.jacobi_bytes);
   w.total = off;
   return w;
@@ -685,7 +765,8 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
 
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
                half_t* out16, float* out32, void* workspace, size_t workspace_bytes, int* sweeps_dev,
-               int stages, hipStream_t s, hipStream_t s2, hipEvent_t ev_fork, hipEvent_t ev_join) {
+               int stages, hipStream_t s, const hipStream_t* side, int nside, hipEvent_t ev_fork,
+               const hipEvent_t* ev_join) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && Nc >= 2 && Ns >= 2 && P >= 1 && P <= 32);
   ARG_CHECK(mode == WCT_MODE_NP || mode == WCT_MODE_TF);
   WctCarve w = carve(workspace, C, Nc, Ns, P);
@@ -717,21 +798,31 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
                      w.cov_partial, w.A, C, w.nsplit, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps);
   }
   if (stages & WCT_STAGE_EIG) {
-    if (s2 && P >= 2) {
+    if (nside > 0 && P >= 2) {
       // The eigensolver alternates a latency-bound kernel on a few workgroups (pair problems) with a
-      // chip-wide tile update.  Two halves of the batch on two streams let one half's pair problems
-      // hide under the other half's tile update.
-      const int n0 = P, n1 = 2 * P - n0;
-      const size_t b0 = (jacobi_workspace_bytes(C, n0) + 255) & ~(size_t)255;
+      // chip-wide tile update.  Splitting the batch into groups on separate streams lets one group's
+      // pair problems hide under the other groups' tile updates.
+      int ngrp = nside + 1;
+      if (ngrp > P) ngrp = P;
+      if (ngrp > 4) ngrp = 4;
+      JacobiGroup grp[4];
       HIP_TRY(hipEventRecord(ev_fork, s));
-      HIP_TRY(hipStreamWaitEvent(s2, ev_fork, 0));
-      JacobiGroup grp[2];
-      if ((rc = jacobi_make_group(&grp[0], w.A, w.V, C, n0, w.jacobi_ws, b0, sweeps_dev, s))) return rc;
-      if ((rc = jacobi_make_group(&grp[1], w.A + (size_t)n0 * cc, w.V + (size_t)n0 * cc, C, n1, (char*)w.jacobi_ws + b0,
-                                  w.jacobi_bytes - b0, sweeps_dev ? sweeps_dev + n0 : nullptr, s2))) return rc;
-      if ((rc = jacobi_dispatch(grp, 2, C))) return rc;
-      HIP_TRY(hipEventRecord(ev_join, s2));
-      HIP_TRY(hipStreamWaitEvent(s, ev_join, 0));
+      size_t off = 0;
+      int m0 = 0;
+      for (int g = 0; g < ngrp; ++g) {
+        const int n = (2 * P * (g + 1)) / ngrp - (2 * P * g) / ngrp;
+        const size_t bytes = (jacobi_workspace_bytes(C, n) + 255) & ~(size_t)255;
+        hipStream_t sg = g == 0 ? s : side[g - 1];
+        if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ev_fork, 0));
+        if ((rc = jacobi_make_group(&grp[g], w.A + (size_t)m0 * cc, w.V + (size_t)m0 * cc, C, n, (char*)w.jacobi_ws + off,
+                                    bytes, sweeps_dev ? sweeps_dev + m0 : nullptr, sg))) return rc;
+        off += bytes; m0 += n;
+      }
+      if ((rc = jacobi_dispatch(grp, ngrp, C))) return rc;
+      for (int g = 1; g < ngrp; ++g) {
+        HIP_TRY(hipEventRecord(ev_join[g - 1], side[g - 1]));
+        HIP_TRY(hipStreamWaitEvent(s, ev_join[g - 1], 0));
+      }
     } else {
       if ((rc = launch_jacobi_eigh(w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, s))) return rc;
     }
