@@ -32,7 +32,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 template <int TH, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
   constexpr int PH = TH + 2;
   constexpr int MT = (TH / 2) / WM;          // 32-pixel MFMA tiles per wave
   constexpr int NT = (BN / 32) / WN;         // 32-channel MFMA tiles per wave
@@ -42,12 +42,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles
   constexpr int W_PER_THREAD = (W_ITEMS + 255) / 256;
   constexpr int PATCH_BYTES = PH * PITCH * 64;
   constexpr int W_BYTES = BN * 64;
-  constexpr int DUMP_OFF = 2 * PATCH_BYTES + 2 * W_BYTES;   // 4 KiB dump area (relative to smem)
+  constexpr int DUMP_OFF = PATCH_BYTES + 2 * W_BYTES;   // 4 KiB dump area (relative to smem)
+  // Register-prefetching the next K-chunk's halo patch costs PATCH_PER_THREAD x 4 VGPRs for the whole
+  // loop; the tall tile spends them on accumulators instead and reloads the patch at the (rare) chunk
+  // boundary, where the second resident block of the CU covers the bubble.
+  constexpr bool PREFETCH_PATCH = TH <= 16;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS map: patch buffers at [0, 2*PATCH_BYTES), weight buffers after them
-  auto patch_buf = [&](int i) -> unsigned char* { return smem + i * PATCH_BYTES; };
-  auto w_buf = [&](int i) -> unsigned char* { return smem + 2 * PATCH_BYTES + i * W_BYTES; };
+  // LDS map: ONE patch buffer at 0 (it changes every 9th iteration only), two weight buffers, dump
+  unsigned char* const patch_lds = smem;
+  auto w_buf = [&](int i) -> unsigned char* { return smem + PATCH_BYTES + i * W_BYTES; };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles
     int n = valid ? item >> 2 : 0;
     int chunk = item & 3;
     w_src[i] = valid ? (n0 + n) * 9 * p.Cin + chunk * 8 : 0;
-    w_dst[i] = valid ? (n * 4 + (chunk ^ ((n >> 2) & 3))) * 16 : DUMP_OFF + tid * 16;
+    w_dst[i] = valid ? PATCH_BYTES + (n * 4 + (chunk ^ ((n >> 2) & 3))) * 16 : DUMP_OFF + tid * 16;
   }
 
   // --- fragment read offsets
@@ -139,10 +143,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles
     *reinterpret_cast<u32x4*>(smem + patch_dst[i]) = patch_regs[i];
 #pragma unroll
   for (int i = 0; i < W_PER_THREAD; ++i)
-    *reinterpret_cast<u32x4*>(smem + 2 * PATCH_BYTES + w_dst[i]) = w_regs[i];
+    *reinterpret_cast<u32x4*>(smem + w_dst[i]) = w_regs[i];
   __syncthreads();
 
-  int pbuf = 0;
   for (int it = 0; it < n_iter; ++it) {
     const int chunk_i = it / 9;
     const int tap = it - chunk_i * 9;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles
 #pragma unroll
       for (int i = 0; i < W_PER_THREAD; ++i)
         w_regs[i] = *reinterpret_cast<const u32x4*>(p.w + w_src[i] + wbase);
-      if (next_patch) {
+      if (PREFETCH_PATCH && next_patch) {
         const int cbase = nchunk * BK;
 #pragma unroll
         for (int i = 0; i < PATCH_PER_THREAD; ++i)
@@ -168,7 +171,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles
     }
 
     // 2) MFMAs on the current stage
-    const unsigned char* pl = patch_buf(pbuf);
     const unsigned char* wl = w_buf(wbuf);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -181,23 +183,30 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs p, int tiles
         const int py = (wm * MT + mt) * 2 + frag_py + ky;
         const int px = frag_px + kx;
         const int off = ((py * PITCH + px) * 4 + (chunk ^ ((px >> 2) & 3))) * 16;
-        half8 bfrag = *reinterpret_cast<const half8*>(pl + off);
+        half8 bfrag = *reinterpret_cast<const half8*>(patch_lds + off);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[nt], bfrag, acc[nt][mt], 0, 0, 0);
       }
     }
 
-    // 3) park the prefetched stage in the other LDS buffers
+    // 3) park the prefetched weights in the other buffer; at a chunk boundary replace the patch
+    //    once every wave has finished reading it
     if (has_next) {
 #pragma unroll
       for (int i = 0; i < W_PER_THREAD; ++i)
-        *reinterpret_cast<u32x4*>(smem + 2 * PATCH_BYTES + (wbuf ^ 1) * W_BYTES * (w_dst[i] < DUMP_OFF) + w_dst[i]) = w_regs[i];
+        *reinterpret_cast<u32x4*>(smem + (wbuf ^ 1) * W_BYTES * (w_dst[i] < DUMP_OFF) + w_dst[i]) = w_regs[i];
       if (next_patch) {
+        __syncthreads();
+        if (!PREFETCH_PATCH) {
+          const int cbase = (chunk_i + 1) * BK;
+#pragma unroll
+          for (int i = 0; i < PATCH_PER_THREAD; ++i)
+            patch_regs[i] = *reinterpret_cast<const u32x4*>(xb + patch_src[i] + cbase);
+        }
 #pragma unroll
         for (int i = 0; i < PATCH_PER_THREAD; ++i)
-          *reinterpret_cast<u32x4*>(smem + (pbuf ^ 1) * PATCH_BYTES * (patch_dst[i] < DUMP_OFF) + patch_dst[i]) = patch_regs[i];
-        pbuf ^= 1;
+          *reinterpret_cast<u32x4*>(smem + patch_dst[i]) = patch_regs[i];
       }
     }
     __syncthreads();
@@ -243,7 +252,7 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
   const int n_tiles = a.Cout / BN;
   constexpr int PH = TH + 2;
-  const size_t lds = 2 * (size_t)PH * PITCH * 64 + 2 * (size_t)BN * 64 + 4096;
+  const size_t lds = (size_t)PH * PITCH * 64 + 2 * (size_t)BN * 64 + 4096;
   dim3 grid(tiles_x * tiles_y * n_tiles, a.B);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
   HIP_TRY(hipGetLastError());
@@ -253,8 +262,11 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
 int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK(a.Cin % BK == 0 && a.Cout % 64 == 0 && a.H > 1 && a.W > 1 && a.B > 0);
   ARG_CHECK(!a.upsample || (a.H % 2 == 0 && a.W % 2 == 0));
-  // pick the largest tile that still gives the chip >= ~1 block per CU
+  // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
   const long px16 = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.B;
+  const long px32 = (long)cdiv(a.W, TW) * cdiv(a.H, 32) * a.B;
+  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) return launch_conv_cfg<16, 128, 2, 2>(a, s);
+  if (px32 * (a.Cout / 64) >= 512) return launch_conv_cfg<32, 64, 4, 1>(a, s);      // 512 px x 64 ch
   if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_conv_cfg<16, 128, 2, 2>(a, s);
   if (px16 * (a.Cout / 64) >= 256) return launch_conv_cfg<16, 64, 4, 1>(a, s);
   return launch_conv_cfg<8, 64, 2, 2>(a, s);
