@@ -1,4 +1,5 @@
 """GPU parity tests, layer and pipeline level (encoder, decoders, WCT.predict)."""
+import os
 import numpy as np
 import pytest
 
@@ -160,3 +161,30 @@ def test_wct_facade_and_batch(ctx, weights):
         assert np.array_equal(outs[i], model.predict(cs[i], ss[i], alpha=0.8)), i
     for p in (dc, ds, do):
         sess.dev_free(p)
+
+
+def test_stylize_cli_end_to_end(tmp_path, ctx, weights):
+    """python -m wct_tf_amd.stylize with the reference's flags: content x style loop, --keep-colors,
+    --passes, --concat, output naming (stylize.py:70-117)."""
+    from wct_tf_amd import utils
+    from wct_tf_amd.stylize import main
+    cdir, sdir, odir = tmp_path / 'c', tmp_path / 's', tmp_path / 'o'
+    cdir.mkdir(); sdir.mkdir()
+    utils.save_img(str(cdir / 'a.png'), synthetic_image(1, 64, 80))
+    utils.save_img(str(cdir / 'b.png'), synthetic_image(2, 64, 64))
+    utils.save_img(str(sdir / 'st.png'), synthetic_image(3, 96, 96))
+    n = main(['--relu-targets', 'relu2_1', 'relu1_1', '--synthetic-weights', '42', '--content-path', str(cdir),
+              '--style-path', str(sdir), '--out-path', str(odir), '--alpha', '0.8', '--style-size', '64',
+              '--crop-size', '48', '--keep-colors', '--passes', '2', '--concat'])
+    assert n == 2
+    out = utils.get_img(str(odir / 'a_st.png'))
+    assert out.shape == (64, 64 + 80, 3)
+    assert os.path.exists(str(odir / 'b_st.png'))
+    # same thing by hand through the op-level API
+    from wct_tf_amd import ops
+    style = utils.center_crop(utils.resize_to(utils.get_img(str(sdir / 'st.png')), 64), 48)
+    content = utils.get_img(str(cdir / 'a.png'))
+    style = ops.preserve_colors_np(style, content, ctx=ctx)
+    x = ctx.stylize(content, style, ['relu2_1', 'relu1_1'], alpha=0.8)
+    x = ctx.stylize(x, style, ['relu2_1', 'relu1_1'], alpha=0.8)
+    assert np.array_equal(out[:, 64:], x)
