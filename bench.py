@@ -26,6 +26,7 @@ import numpy as np  # noqa: E402
 LEVELS = ['relu5_1', 'relu4_1', 'relu3_1', 'relu2_1', 'relu1_1']
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 HBM_PEAK_GBS = 8000.0
+PMC_BATCH = 16                            # batch the committed PMC passes were collected at
 
 
 def conv_flops_per_frame(size):
@@ -62,7 +63,7 @@ def pmc_traffic(batch, size):
     separate runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read
     from inside this process, so the figure is the profile of this exact workload; null otherwise."""
     path = os.path.join(ROOT, 'profiles', 'r01_v3_pmc_conv3x3.json')
-    if batch != 8 or size != 512 or not os.path.exists(path):
+    if batch != PMC_BATCH or size != 512 or not os.path.exists(path):
         return None
     return json.load(open(path))['hbm_bytes_per_launch_corrected']
 
@@ -86,7 +87,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=8, help='independent content/style pairs per GPU per step')
+    ap.add_argument('--batch', type=int, default=16, help='independent content/style pairs per GPU per step')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--alpha', type=float, default=0.8)
     ap.add_argument('--no-cpu-baseline', action='store_true')

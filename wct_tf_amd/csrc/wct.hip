@@ -272,7 +272,8 @@ __device__ __forceinline__ int pair_index(int r, int bi, int bj) {
 }
 
 constexpr float JACOBI_ROT_TOL = 1e-6f;    // skip rotations below this relative size
-constexpr float JACOBI_CONV_TOL = 2e-3f;   // a sweep that never saw more than this is the last one (quadratic convergence)
+constexpr float JACOBI_CONV_TOL = 1e-2f;   // a sweep that never saw more than this is the last one (quadratic convergence;
+                                           // measured: WCT error vs the oracle identical for 2e-3 and 1e-2, 100x worse at 5e-2)
 constexpr float JACOBI_FLOOR = 1e-6f;      // both diagonals below this: the pair cannot reach the 1e-5 cut-off
 
 // rotation (c, s) that annihilates a_pq; `off` = pre-rotation relative size (0 if skipped).
@@ -496,11 +497,11 @@ __global__ void jacobi_init_kernel(float* V, JacobiState* st, int C) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { st[m].offmax = 0u; st[m].done = 0; st[m].sweeps = 0; st[m].pad = 0; }
 }
 
-__global__ void jacobi_check_kernel(JacobiState* st, int nmat) {
+__global__ void jacobi_check_kernel(JacobiState* st, int nmat, float conv_tol) {
   const int m = threadIdx.x;
   if (m >= nmat || st[m].done) return;
   st[m].sweeps += 1;
-  if (__uint_as_float(st[m].offmax) < JACOBI_CONV_TOL) st[m].done = 1;
+  if (__uint_as_float(st[m].offmax) < conv_tol) st[m].done = 1;
   st[m].offmax = 0u;
 }
 
@@ -548,8 +549,9 @@ static void jacobi_enqueue_sweep(const JacobiGroup* grp, int ngrp, int C) {
       hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3((M2 / 2) * (M2 / 2)), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
       hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3(2 * npair * npair, G.nmat), dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
     }
+  static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
   for (int g = 0; g < ngrp; ++g)
-    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].nmat);
+    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].nmat, conv_tol);
 }
 
 template <int M2>
