@@ -42,7 +42,7 @@ struct Decoder {
   bool loaded = false;
   std::vector<PlanStep> plan;
   std::vector<ConvLayer> convs;    // every conv but the last
-  float* last_w = nullptr;         // [576][3] fp32
+  half_t* last_w = nullptr;        // [9][32][3][2] fp16 pairs (see ConvLastArgs)
   float* last_b = nullptr;
 };
 
@@ -335,8 +335,12 @@ extern "C" int wct_set_decoder(wct_ctx* c, int level, const float* const* w, con
   for (auto& s : d.plan) {
     if (s.kind != 'C') continue;
     if (s.cout == 3) {
-      // [3][3][64][3] HWIO is already [(tap*64+cin)][3]
-      TRY(upload(c, w[i], (size_t)576 * 3 * sizeof(float), (void**)&d.last_w));
+      // HWIO [3][3][64][3] = [(tap*64+cin)][3] -> [(tap*32+cin/2)][3][2] fp16 pairs
+      std::vector<half_t> w16((size_t)576 * 3);
+      for (int t = 0; t < 9 * 32; ++t)
+        for (int o = 0; o < 3; ++o)
+          for (int h = 0; h < 2; ++h) w16[((size_t)t * 3 + o) * 2 + h] = (half_t)w[i][((size_t)t * 2 + h) * 3 + o];
+      TRY(upload(c, w16.data(), w16.size() * sizeof(half_t), (void**)&d.last_w));
       TRY(upload(c, b[i], 3 * sizeof(float), (void**)&d.last_b));
     } else {
       d.convs.emplace_back();
@@ -426,7 +430,7 @@ static int run_decoder(wct_ctx* c, int level, const half_t* feat16, int B, int h
     if (s.cout == 3) {
       ARG_CHECK(up == 0);
       ConvLastArgs a;
-      a.x = cur; a.w = d.last_w; a.bias = d.last_b; a.y = img_out; a.B = B; a.H = h; a.W = w;
+      a.x = cur; a.w16 = d.last_w; a.bias = d.last_b; a.y = img_out; a.B = B; a.H = h; a.W = w;
       const double px = (double)B * h * w;
       ProfScope ps(c, 2, 2.0 * px * 576 * 3, px * (128 + 12));
       TRY(launch_conv_last(a, c->stream));

@@ -376,6 +376,8 @@ __global__ __launch_bounds__(256) void conv_last_kernel(ConvLastArgs p, int tile
   const int ly = tid >> 4, lx = tid & 15;
   const int oy = y0 + ly, ox = x0 + lx;
   float a0 = p.bias[0], a1 = p.bias[1], a2 = p.bias[2];
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  const half2_t* w2 = reinterpret_cast<const half2_t*>(p.w16);     // [tap][cin/2][3] pairs of fp16 weights
 #pragma unroll 1
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
@@ -384,13 +386,13 @@ __global__ __launch_bounds__(256) void conv_last_kernel(ConvLastArgs p, int tile
 #pragma unroll
     for (int chunk = 0; chunk < 8; ++chunk) {
       half8 h = *reinterpret_cast<const half8*>(patch + (pix * 8 + (chunk ^ ((px >> 1) & 7))) * 16);
-      const float* wk = p.w + (tap * 64 + chunk * 8) * 3;
+      const half2_t* wk = w2 + (tap * 32 + chunk * 4) * 3;          // uniform address -> scalar loads
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float xv = (float)h[j];
-        a0 = fmaf(xv, wk[j * 3 + 0], a0);
-        a1 = fmaf(xv, wk[j * 3 + 1], a1);
-        a2 = fmaf(xv, wk[j * 3 + 2], a2);
+      for (int j = 0; j < 4; ++j) {
+        half2_t xv = {h[2 * j], h[2 * j + 1]};
+        a0 = __builtin_amdgcn_fdot2(xv, wk[j * 3 + 0], a0, false);  // v_dot2_f32_f16: 2 MACs, fp32 accumulate
+        a1 = __builtin_amdgcn_fdot2(xv, wk[j * 3 + 1], a1, false);
+        a2 = __builtin_amdgcn_fdot2(xv, wk[j * 3 + 2], a2, false);
       }
     }
   }

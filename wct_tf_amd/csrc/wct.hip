@@ -91,12 +91,61 @@ struct GemmArgs {
 
 constexpr int GK = 16;
 
+// one operand tile (GK x BX, k-major in LDS) moves global -> registers -> LDS in two phases so the
+// loads of K-step t+1 are in flight while the MFMAs of step t run
+template <int BX>
+struct GemmStage {
+  static constexpr int NV = GK * BX / 4 / 256;      // float4 per thread
+  f32x4 v[NV];
+  // kmajor: element (k, x) at src[k*ld + x];  else element (x, k) at src[x*ld + k]
+  __device__ __forceinline__ void load(const float* src, int ld, bool kmajor, int k0, int kend, int x0, int X,
+                                       const float* sub_x, const float* sub_k, const float* scale_k, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int item = tid + i * 256;
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      if (kmajor) {
+        const int k = item / (BX / 4), x4 = item % (BX / 4);
+        const int gk = k0 + k, gx = x0 + x4 * 4;
+        if (gk < kend && gx < X) {
+          t = *reinterpret_cast<const f32x4*>(src + (size_t)gk * ld + gx);
+          if (sub_x) t -= *reinterpret_cast<const f32x4*>(sub_x + gx);
+        }
+      } else {
+        const int x = item / (GK / 4), k4 = item % (GK / 4);
+        const int gx = x0 + x, gk = k0 + k4 * 4;
+        if (gx < X && gk < kend) {          // K and ksplit are multiples of 4
+          t = *reinterpret_cast<const f32x4*>(src + (size_t)gx * ld + gk);
+          if (sub_k) t -= *reinterpret_cast<const f32x4*>(sub_k + gk);
+          if (scale_k) t *= *reinterpret_cast<const f32x4*>(scale_k + gk);
+        }
+      }
+      v[i] = t;
+    }
+  }
+  __device__ __forceinline__ void store(float* lds /* [GK][BX+4] */, bool kmajor, int tid) const {
+    constexpr int P = BX + 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int item = tid + i * 256;
+      if (kmajor) {
+        const int k = item / (BX / 4), x4 = item % (BX / 4);
+        *reinterpret_cast<f32x4*>(lds + k * P + x4 * 4) = v[i];
+      } else {
+        const int x = item / (GK / 4), k4 = item % (GK / 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[(k4 * 4 + j) * P + x] = v[i][j];
+      }
+    }
+  }
+};
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave (2x2 waves)
   constexpr int PA = BM + 4, PB = BN + 4;
-  __shared__ __attribute__((aligned(16))) float As[GK][PA];
-  __shared__ __attribute__((aligned(16))) float Bs[GK][PB];
+  __shared__ __attribute__((aligned(16))) float As[GK * PA];
+  __shared__ __attribute__((aligned(16))) float Bs[GK * PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -118,64 +167,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  GemmStage<BM> sa;
+  GemmStage<BN> sb;
+  if (kbeg < kend) {
+    sa.load(p.A, p.lda, p.a_kmajor, kbeg, kend, m0, p.M, p.a_sub_m, p.a_sub_k, p.a_scale_k, tid);
+    sb.load(p.B, p.ldb, p.b_kmajor, kbeg, kend, n0, p.N, p.b_sub_n, nullptr, nullptr, tid);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    // ---- stage A tile: As[k][m]
-    if (p.a_kmajor) {
-      for (int item = tid; item < GK * BM / 4; item += 256) {
-        int k = item / (BM / 4), m4 = item % (BM / 4);
-        int gk = k0 + k, gm = m0 + m4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gk < kend && gm < p.M) {
-          v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gk * p.lda + gm);
-          if (p.a_sub_m) v -= *reinterpret_cast<const f32x4*>(p.a_sub_m + gm);
-        }
-        *reinterpret_cast<f32x4*>(&As[k][m4 * 4]) = v;
-      }
-    } else {
-      for (int item = tid; item < BM * GK / 4; item += 256) {
-        int m = item / (GK / 4), k4 = item % (GK / 4);
-        int gm = m0 + m, gk = k0 + k4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gm < p.M && gk < kend) {     // K and ksplit are multiples of 4
-          v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gm * p.lda + gk);
-          if (p.a_sub_k) v -= *reinterpret_cast<const f32x4*>(p.a_sub_k + gk);
-          if (p.a_scale_k) v *= *reinterpret_cast<const f32x4*>(p.a_scale_k + gk);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) As[k4 * 4 + j][m] = v[j];
-      }
-    }
-    // ---- stage B tile: Bs[k][n]
-    if (p.b_kmajor) {
-      for (int item = tid; item < GK * BN / 4; item += 256) {
-        int k = item / (BN / 4), n4 = item % (BN / 4);
-        int gk = k0 + k, gn = n0 + n4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gk < kend && gn < p.N) {
-          v = *reinterpret_cast<const f32x4*>(p.B + (size_t)gk * p.ldb + gn);
-          if (p.b_sub_n) v -= *reinterpret_cast<const f32x4*>(p.b_sub_n + gn);
-        }
-        *reinterpret_cast<f32x4*>(&Bs[k][n4 * 4]) = v;
-      }
-    } else {
-      for (int item = tid; item < BN * GK / 4; item += 256) {
-        int n = item / (GK / 4), k4 = item % (GK / 4);
-        int gn = n0 + n, gk = k0 + k4 * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (gn < p.N && gk < kend) v = *reinterpret_cast<const f32x4*>(p.B + (size_t)gn * p.ldb + gk);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Bs[k4 * 4 + j][n] = v[j];
-      }
-    }
+    sa.store(As, p.a_kmajor, tid);
+    sb.store(Bs, p.b_kmajor, tid);
     __syncthreads();
+    if (k0 + GK < kend) {
+      sa.load(p.A, p.lda, p.a_kmajor, k0 + GK, kend, m0, p.M, p.a_sub_m, p.a_sub_k, p.a_scale_k, tid);
+      sb.load(p.B, p.ldb, p.b_kmajor, k0 + GK, kend, n0, p.N, p.b_sub_n, nullptr, nullptr, tid);
+    }
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2) {
       float a[TM], b[TN];
       const int kr = kk + (lane >> 5);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[kr][(wm * TM + i) * 32 + (lane & 31)];
+      for (int i = 0; i < TM; ++i) a[i] = As[kr * PA + (wm * TM + i) * 32 + (lane & 31)];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[kr][(wn * TN + j) * 32 + (lane & 31)];
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kr * PB + (wn * TN + j) * 32 + (lane & 31)];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -713,7 +726,7 @@ static void cov_split(int C, int Nmax, int P, int* nsplit, int* ksplit) {
   int want = 512 / tiles;                      // ~2 waves of blocks over 256 CUs
   if (want < 1) want = 1;
   int ks = cdiv(cdiv(Nmax, want), GK) * GK;
-  if (ks < 256) ks = 256;
+  if (ks < 256) ks = 256;       // multiple of GK = 32
   *ksplit = ks;
   *nsplit = cdiv(Nmax, ks);
 }
