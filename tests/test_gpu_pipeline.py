@@ -188,3 +188,46 @@ def test_stylize_cli_end_to_end(tmp_path, ctx, weights):
     x = ctx.stylize(content, style, ['relu2_1', 'relu1_1'], alpha=0.8)
     x = ctx.stylize(x, style, ['relu2_1', 'relu1_1'], alpha=0.8)
     assert np.array_equal(out[:, 64:], x)
+
+
+def test_full_size_properties_512(ctx, weights):
+    """BASELINE config 3 size (512x512, 5 levels): size-independent properties instead of an oracle run.
+    (1) determinism: two runs are bit-identical; (2) batching: the batched device entry point equals the
+    single-pair call bit for bit; (3) alpha = 0 makes every transform the identity on the content features,
+    so the style image must not matter; (4) per-level WCT at alpha = 1 reproduces the style mean and
+    covariance on the GPU's own full-size features (the defining property of the transform)."""
+    from wct_tf_amd import _lib
+    c = synthetic_image(1000, 512, 512)
+    s = synthetic_image(2000, 512, 512)
+    s2 = synthetic_image(2001, 512, 512)
+    a = ctx.stylize(c, s, RELU_TARGETS, alpha=0.8)
+    b = ctx.stylize(c, s, RELU_TARGETS, alpha=0.8)
+    assert a.shape == (512, 512, 3) and a.dtype == np.uint8
+    assert np.array_equal(a, b)
+    cs = np.stack([c, synthetic_image(1001, 512, 512)])
+    ss = np.stack([s, s2])
+    dc, ds, do = ctx.dev_alloc(cs.nbytes), ctx.dev_alloc(ss.nbytes), ctx.dev_alloc(cs.nbytes)
+    ctx.h2d(dc, cs); ctx.h2d(ds, ss)
+    ctx.stylize_batch_dev(dc, 512, 512, ds, 512, 512, 2, RELU_TARGETS, 0.8, do)
+    ctx.sync()
+    outs = np.empty_like(cs)
+    ctx.d2h(outs, do)
+    for p in (dc, ds, do):
+        ctx.dev_free(p)
+    assert np.array_equal(outs[0], a)
+    z1 = ctx.stylize(c, s, RELU_TARGETS, alpha=0.0)
+    z2 = ctx.stylize(c, s2, RELU_TARGETS, alpha=0.0)
+    assert np.array_equal(z1, z2)
+    s01 = np.float32(s / 255.)
+    c01 = np.float32(c / 255.)
+    for relu in ('relu5_1', 'relu3_1', 'relu1_1'):
+        fc, fs = ctx.encode(c01, relu), ctx.encode(s01, relu)
+        ch = fc.shape[-1]
+        out, sweeps = ctx.transform(fc.reshape(-1, ch), fs.reshape(-1, ch), 1.0, _lib.WCT_TF, return_sweeps=True)
+        fs2 = fs.reshape(-1, ch).astype(np.float64)
+        o2 = out.astype(np.float64)
+        assert np.abs(o2.mean(0) - fs2.mean(0)).max() < 1e-3 * max(1.0, np.abs(fs2.mean(0)).max())
+        cov_o, cov_s = np.cov(o2.T), np.cov(fs2.T)
+        err = np.linalg.norm(cov_o - cov_s) / np.linalg.norm(cov_s)
+        print(relu, 'sweeps', sweeps, 'cov err %.2e' % err)
+        assert err < 5e-3

@@ -723,7 +723,7 @@ static int wct_nslab(int N) { int s = cdiv(N, 64); return s < 1 ? 1 : (s > 256 ?
 
 static void cov_split(int C, int Nmax, int P, int* nsplit, int* ksplit) {
   const int tiles = (C >= 128 ? (C / 128) * (C / 128) : 1) * P;
-  int want = 512 / tiles;                      // ~2 waves of blocks over 256 CUs
+  int want = 128 / tiles;                      // x2 matrices per pair: one block per CU at P = 1, more with P
   if (want < 1) want = 1;
   int ks = cdiv(cdiv(Nmax, want), GK) * GK;
   if (ks < 256) ks = 256;       // multiple of GK = 32
@@ -735,7 +735,7 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   WctCarve w;
   const int Nmax = Nc > Ns ? Nc : Ns;
   w.nslab = wct_nslab(Nmax);
-  cov_split(C, Nmax, P, &w.nsplit, &w.ksplit);
+  cov_split(C, Nmax, 1, &w.nsplit, &w.ksplit);   // independent of P: a pair's result must not depend on its batch
   size_t off = 0;
   char* b = reinterpret_cast<char*>(base);
   auto take = [&](size_t bytes) { void* p = b ? b + off : nullptr; off += align_up(bytes); return p; };
