@@ -18,7 +18,7 @@ __global__ __launch_bounds__((N / 2) * (N / 2)) void probe_kernel(const float* A
   __syncthreads();
   long long t0 = clock64();
   int cur = 0;
-  for (int rep = 0; rep < 4; ++rep) cur = jacobi_sets<MODE, N>(SQ, tid, my_off);
+  for (int rep = 0; rep < 4; ++rep) cur = jacobi_sets<MODE, N>(SQ, sm + 4 * N * (N + 1), tid, my_off);
   long long t1 = clock64();
   if (tid == 0) { out[0] = t1 - t0; out[2] = (long long)(my_off * 1e6f) + cur; }
 }
@@ -26,7 +26,7 @@ __global__ __launch_bounds__((N / 2) * (N / 2)) void probe_kernel(const float* A
 template <int MODE, int N> void run(const float* dA, long long* dout, const char* name, int nsets) {
   long long h[4];
   for (int it = 0; it < 2; ++it) {
-    hipLaunchKernelGGL((probe_kernel<MODE, N>), dim3(16), dim3((N / 2) * (N / 2)), 2 * N * (N + 1) * 8, 0, dA, dout);
+    hipLaunchKernelGGL((probe_kernel<MODE, N>), dim3(16), dim3((N / 2) * (N / 2)), 2 * N * (N + 1) * 8 + 3 * N * 4, 0, dA, dout);
     hipDeviceSynchronize();
   }
   hipMemcpy(h, dout, sizeof(h), hipMemcpyDeviceToHost);

@@ -334,12 +334,24 @@ __device__ __forceinline__ void sweep_pair(int j, int s, int& p, int& q) {
   if (MODE == SWEEP_CROSS) { p = j; q = NP + ((j + s) & (NP - 1)); }
   else { const int base = j & (NP / 2) ? NP : 0, jj = j & (NP / 2 - 1); p = base + rr_idx(jj, s, NP); q = base + rr_idx(NP - 1 - jj, s, NP); }
 }
+//
+// In CROSS mode the three values every thread needs for rotation(l) -- S[p][p], S[q][q], S[p][q] --
+// are mirrored in two small compact arrays (DO: diagonal D[2][N] and pair elements O[2][N/2]), kept
+// current by the threads that own them; reading them straight out of the float2 image costs three
+// 4-way bank-conflicted loads per thread and set (the diagonal has stride 2(N+2) dwords).
 template <int MODE, int N>
-__device__ __forceinline__ int jacobi_sets(f32x2* SQ, int t, float& my_off) {
+__device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& my_off) {
   constexpr int NP = N / 2, PITCH = N + 1, IMG = N * PITCH;
   constexpr int NSETS = MODE == SWEEP_CROSS ? NP : NP - 1;
   const int k = t / NP, l = t % NP;
   const int src_lane = (t & (64 - NP)) | k;      // lane of my wave whose l equals my k
+  float* const Dg = DO;                          // [2][N]
+  float* const Og = DO + 2 * N;                  // [2][NP]
+  if (MODE == SWEEP_CROSS) {
+    if (t < N) Dg[t] = SQ[t * PITCH + t][0];
+    if (t < NP) Og[t] = SQ[t * PITCH + NP + t][0];      // set 0 pairs j with NP + j
+    __syncthreads();
+  }
   int cur = 0;
   for (int s = 0; s < NSETS; ++s) {
     int pk, qk, pl, ql;
@@ -348,7 +360,9 @@ __device__ __forceinline__ int jacobi_sets(f32x2* SQ, int t, float& my_off) {
     const f32x2* C0 = SQ + cur * IMG;
     f32x2* N0 = SQ + (cur ^ 1) * IMG;
     // every LDS read of the set is issued before anything depends on it
-    const float lpp = C0[pl * PITCH + pl][0], lqq = C0[ql * PITCH + ql][0], lpq = C0[pl * PITCH + ql][0];
+    float lpp, lqq, lpq;
+    if (MODE == SWEEP_CROSS) { lpp = Dg[cur * N + pl]; lqq = Dg[cur * N + ql]; lpq = Og[cur * NP + l]; }
+    else { lpp = C0[pl * PITCH + pl][0]; lqq = C0[ql * PITCH + ql][0]; lpq = C0[pl * PITCH + ql][0]; }
     const f32x2 app = C0[pk * PITCH + pl], apq = C0[pk * PITCH + ql];
     const f32x2 aqp = C0[qk * PITCH + pl], aqq = C0[qk * PITCH + ql];
     float cl, sl, offl;
@@ -365,6 +379,11 @@ __device__ __forceinline__ int jacobi_sets(f32x2* SQ, int t, float& my_off) {
     nqp[1] = cl * aqp[1] - sl * aqq[1];  nqq[1] = sl * aqp[1] + cl * aqq[1];
     N0[pk * PITCH + pl] = npp;  N0[pk * PITCH + ql] = npq;
     N0[qk * PITCH + pl] = nqp;  N0[qk * PITCH + ql] = nqq;
+    if (MODE == SWEEP_CROSS) {
+      const int nx = cur ^ 1;
+      if (k == l) { Dg[nx * N + pk] = npp[0]; Dg[nx * N + qk] = nqq[0]; }
+      if (l == ((k + 1) & (NP - 1))) Og[nx * NP + k] = npq[0];     // S[p_k][q_k] of the next set
+    }
     cur ^= 1;
     __syncthreads();
   }
@@ -393,7 +412,8 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2)) void jacobi_diag_kernel(float*
   }
   float my_off = 0.f;
   __syncthreads();
-  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2>(SQ, tid, my_off) : jacobi_sets<SWEEP_CROSS, M2>(SQ, tid, my_off);
+  float* DO = jsm + 4 * M2 * PITCH;                   // after the two float2 images
+  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2>(SQ, DO, tid, my_off) : jacobi_sets<SWEEP_CROSS, M2>(SQ, DO, tid, my_off);
   float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
   for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
   for (int o = 32; o > 0; o >>= 1) my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
@@ -430,10 +450,15 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nthr = M2 == 32 ? 64 : 256;
   const int nblk = C / B, npair = nblk / 2;
+  // A is symmetric: for M2 = 64 only the tiles g <= h are computed, and Y^T is written to (h, g)
+  constexpr bool SYM = M2 == 64;
+  const int n_a_tiles = SYM ? npair * (npair + 1) / 2 : npair * npair;
   int t = blockIdx.x;
-  const bool is_v = t >= npair * npair;
-  if (is_v) t -= npair * npair;
-  const int g = t / npair, h = t % npair;       // for V tiles g is the M2-row block index
+  const bool is_v = t >= n_a_tiles;
+  if (is_v) t -= n_a_tiles;
+  int g, h;                                     // for V tiles g is the M2-row block index
+  if (SYM && !is_v) { g = 0; while (t >= npair - g) { t -= npair - g; ++g; } h = g + t; }
+  else { g = t / npair; h = t % npair; }
   int hi, hj, gi = 0, gj = 0;
   block_pair(h, step, nblk, hi, hj);
   if (!is_v) block_pair(g, step, nblk, gi, gj);
@@ -500,6 +525,17 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
     const int gr = is_v ? g * M2 + row : pair_index<B>(row, gi, gj);
     X[(size_t)gr * C + pair_index<B>(wj + li, hi, hj)] = acc[r];
   }
+  if (SYM && !is_v && g != h) {
+    // mirror tile: transpose through LDS so the global stores stay row-contiguous
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Xs[(wi + (r & 3) + 8 * (r >> 2) + 4 * lk) * PITCH + wj + li] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < M2 * M2; e += nthr) {
+      const int c = e / M2, r = e % M2;           // element Y[r][c] -> A[idx_h(c)][idx_g(r)]
+      X[(size_t)pair_index<B>(c, hi, hj) * C + pair_index<B>(r, gi, gj)] = Xs[r * PITCH + c];
+    }
+  }
 }
 
 __global__ void jacobi_init_kernel(float* V, JacobiState* st, int C) {
@@ -553,14 +589,15 @@ template <int M2>
 static void jacobi_enqueue_sweep(const JacobiGroup* grp, int ngrp, int C) {
   constexpr int B = M2 / 2;
   const int nblk = C / B, npair = nblk / 2;
-  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2);
+  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2) + 3 * M2 * sizeof(float);
   // step -1 rotates the pairs inside each block, steps 0.. the cross pairs of every block pair:
   // each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
   for (int step = -1; step < nblk - 1; ++step)
     for (int g = 0; g < ngrp; ++g) {
       const JacobiGroup& G = grp[g];
       hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3((M2 / 2) * (M2 / 2)), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
-      hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3(2 * npair * npair, G.nmat), dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
+      hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3((M2 == 64 ? npair * (npair + 1) / 2 : npair * npair) + npair * npair, G.nmat),
+                         dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
     }
   static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
   for (int g = 0; g < ngrp; ++g)
