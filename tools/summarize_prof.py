@@ -3,6 +3,7 @@ usage: python tools/summarize_prof.py <prof_dir> <tag>     (expects stats_result
 import json, os, sqlite3, sys
 
 src, tag = sys.argv[1], sys.argv[2]
+batch = sys.argv[3] if len(sys.argv) > 3 else '16'
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
 os.makedirs(out, exist_ok=True)
 
@@ -11,7 +12,7 @@ def q(db, sql):
 
 rows = q('stats_results.db', "select name,total_calls,total_duration,average,percentage from top_kernels")
 with open(os.path.join(out, '%s_kernel_stats.csv' % tag), 'w') as f:
-    f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (batch 8 x 512x512, 5-level); durations in us\n')
+    f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (batch %s x 512x512, 5-level); durations in us\n' % batch)
     f.write('name,calls,total_us,avg_us,percent\n')
     for r in rows:
         f.write('"%s",%d,%.3f,%.3f,%.3f\n' % r)
@@ -22,7 +23,7 @@ for db, ctr in (('fetch_results.db', 'FETCH_SIZE'), ('write_results.db', 'WRITE_
         pmc.setdefault(name, {})[ctr + '_KB_per_launch'] = avg
         pmc[name]['launches_' + ctr] = n
 with open(os.path.join(out, '%s_pmc_hbm.csv' % tag), 'w') as f:
-    f.write('# separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 1 --warmup 1 --no-prof (batch 8 x 512x512)\n')
+    f.write('# separate passes: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 1 --warmup 1 --no-prof (batch %s x 512x512)\n' % batch)
     f.write('# raw counter averages per launch in KB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane)\n')
     f.write('# coalesced streaming read -> hbm_read_bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is uncalibrated (taken as is).\n')
     f.write('kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB,corrected_hbm_MB_per_launch\n')
@@ -38,7 +39,7 @@ for name, d in pmc.items():
         tot_n += n
         tot_f += n * d.get('FETCH_SIZE_KB_per_launch', 0.0)
         tot_w += d.get('launches_WRITE_SIZE', 0) * d.get('WRITE_SIZE_KB_per_launch', 0.0)
-summary = {'workload': 'batch 8 x 512x512, 5-level', 'kernel_class': 'conv3x3_mfma_kernel', 'launches': tot_n,
+summary = {'workload': 'batch %s x 512x512, 5-level' % batch, 'kernel_class': 'conv3x3_mfma_kernel', 'launches': tot_n,
            'fetch_size_KB_per_launch': tot_f / max(1, tot_n), 'write_size_KB_per_launch': tot_w / max(1, tot_n),
            'hbm_bytes_per_launch_corrected': (2 * tot_f + tot_w) * 1024 / max(1, tot_n),
            'correction': '2 x FETCH_SIZE (gfx950 wide-read undercount, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes'}
