@@ -134,7 +134,9 @@ def main():
                               B, LEVELS, args.alpha, C.c_void_p(d_out.data_ptr()))
         if world > 1:
             ctx.sync()                                                     # library stream -> torch stream hand-off
-            return gather_frames(d_out, world, rank)
+            frames = gather_frames(d_out, world, rank)
+            torch.cuda.synchronize()                                       # RCCL must be done with d_out before the
+            return frames                                                  # next step overwrites it on the library stream
         return None
 
     def barrier():
