@@ -72,6 +72,24 @@ def main():
         blob['case%d/coral' % i] = ref_coral.coral_numpy(src / 255., tgt / 255.)
         blob['case%d/preserve' % i] = ref_utils.preserve_colors_np(src, tgt)
     np.savez_compressed(os.path.join(OUT, 'coral_reference.npz'), **blob)
+
+    # .t7 fixture: a small VGG-shaped nn.Sequential, parsed by the REFERENCE's torchfile.py the way
+    # vgg_normalised.py:16-34 does; the arrays it extracts are the golden values for wct_tf_amd/t7.py
+    from oracle.t7_writer import write_vgg_like
+    import torchfile as ref_torchfile      # noqa: E402  (the reference's vendored reader, executed not copied)
+    t7_path = os.path.join(OUT, 'tiny_vgg.t7')
+    write_vgg_like(t7_path, [(None, 3, 3, 1), ('conv1_1', 3, 8, 3), ('conv1_2', 8, 8, 3), ('conv2_1', 8, 16, 3)], seed=3)
+    t7 = ref_torchfile.load(t7_path, force_8bytes_long=True)
+    blob = {}
+    for idx, module in enumerate(t7.modules):
+        name = module.name.decode() if module.name is not None else None
+        if idx == 0:
+            name = 'preprocess'
+        blob['typenames/%d' % idx] = np.frombuffer(module._typename, dtype=np.uint8)
+        if module._typename == b'nn.SpatialConvolution':
+            blob['%s/w_hwio' % name] = module.weight.transpose([2, 3, 1, 0])
+            blob['%s/b' % name] = module.bias
+    np.savez_compressed(os.path.join(OUT, 't7_reference.npz'), **blob)
     print('wrote', os.listdir(OUT))
 
 

@@ -100,3 +100,25 @@ def test_cli_flags_match_reference_and_utils(tmp_path):
     p = str(tmp_path / 'x.png')
     utils.save_img(p, img)
     assert np.array_equal(utils.get_img(p), img)
+
+
+def test_t7_reader_matches_reference_torchfile():
+    """wct_tf_amd/t7.py on tests/golden/tiny_vgg.t7 == what the reference's torchfile.py + the
+    vgg_normalised.py:22-34 walk extracted from the same file (fixture made by oracle/make_golden.py)."""
+    import os
+    from conftest import GOLDEN
+    from wct_tf_amd.t7 import load_t7, vgg_weights_from_t7
+    z = np.load(os.path.join(GOLDEN, 't7_reference.npz'))
+    net = load_t7(os.path.join(GOLDEN, 'tiny_vgg.t7'))
+    assert net._typename == b'nn.Sequential'
+    for idx, module in enumerate(net.modules):
+        assert module._typename == z['typenames/%d' % idx].tobytes()
+    enc = vgg_weights_from_t7(os.path.join(GOLDEN, 'tiny_vgg.t7'))
+    names = sorted({k.split('/')[0] for k in z.files if not k.startswith('typenames')})
+    assert names == sorted(enc) == ['conv1_1', 'conv1_2', 'conv2_1', 'preprocess']
+    for n in names:
+        assert np.array_equal(enc[n][0], z[n + '/w_hwio']) and enc[n][0].dtype == np.float32
+        assert np.array_equal(enc[n][1], z[n + '/b'])
+    with pytest.raises(ValueError):
+        from wct_tf_amd.t7 import T7Reader
+        T7Reader(memoryview(b'\x04\x00\x00\x00\x01\x00'), 8).read()      # truncated

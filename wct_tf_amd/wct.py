@@ -46,7 +46,11 @@ class WCT(object):
             if vgg_path is not None:
                 if not os.path.exists(vgg_path):
                     raise Exception('No VGG weights found at {}'.format(vgg_path))
-                weights['encoder'] = load_weights(vgg_path)['encoder']
+                if vgg_path.endswith('.t7'):                 # the reference's own format (vgg_normalised.py:16)
+                    from .t7 import vgg_weights_from_t7
+                    weights['encoder'] = vgg_weights_from_t7(vgg_path)
+                else:
+                    weights['encoder'] = load_weights(vgg_path)['encoder']
             for relu_target, checkpoint_dir in zip(relu_targets, checkpoints or []):
                 path = checkpoint_dir
                 if os.path.isdir(path):
