@@ -39,7 +39,8 @@ enum wct_mode { WCT_NP = 0, WCT_TF = 1 };
 /* flags for wct_stylize* */
 enum wct_flags {
   WCT_FLAG_ADAIN = 1,      /* --adain: AdaIN at every level instead of WCT (model.py:148-158) */
-  WCT_FLAG_MODE_NP = 2     /* use wct_np semantics instead of the graph's wct_tf */
+  WCT_FLAG_MODE_NP = 2,    /* use wct_np semantics instead of the graph's wct_tf */
+  WCT_FLAG_SWAP5 = 4       /* --swap5: style-swap at relu5_1 (wins over ADAIN there, model.py:148-152) */
 };
 
 /* ---- lifecycle: replaces WCT.__init__'s tf.Session setup (wct.py:29-44) ---- */
@@ -72,6 +73,14 @@ int wct_transform(wct_ctx* ctx, const float* content, int Nc, const float* style
 /* adain (ops.py:282-294), epsilon as in the reference signature */
 int wct_adain(wct_ctx* ctx, const float* content, int Nc, const float* style, int Ns,
               int C, float alpha, float epsilon, float* out);
+/* wct_style_swap (ops.py:145-278): content [hc*wc][C], style [hs*ws][C], out [hc*wc][C]; `alpha` is the
+ * reference's ss_alpha; eps < 0 = its default 1e-8.  (hc, wc) must survive the patch/stride round trip
+ * (utils.swap_filter_fit, wct.py:84-90) -- always true for stride 1. */
+int wct_style_swap(wct_ctx* ctx, const float* content, int hc, int wc, const float* style, int hs, int ws,
+                   int C, float alpha, int patch_size, int stride, float eps, float* out);
+/* style-swap settings used by wct_stylize* when WCT_FLAG_SWAP5 is set: WCT(ss_patch_size, ss_stride)
+ * (wct.py:17-18) and predict(ss_alpha) (wct.py:70).  Defaults 0.6 / 3 / 1 (stylize.py:34-37). */
+int wct_set_style_swap(wct_ctx* ctx, float ss_alpha, int patch_size, int stride);
 /* symmetric eigendecomposition used in place of tf.svd / np.linalg.svd (ops.py:53-55,110,123):
  * A [nmat][C][C] in; evals [nmat][C], evecs [nmat][C][C] (columns) out. */
 int wct_eigh(wct_ctx* ctx, const float* A, int C, int nmat, float* evals, float* evecs,

@@ -15,7 +15,7 @@ Parity status:
     independent torch-CPU implementation in ``tests/test_oracle.py``.
 """
 from .wct_oracle import (wct_np, wct_tf, adain, coral_numpy, mat_sqrt_numpy,
-                         preserve_colors_np)
+                         preserve_colors_np, style_swap, wct_style_swap)
 from .net_oracle import (conv3x3_reflect, maxpool2x2_same, upsample2x_nearest,
                          encode, decode, stylize, preprocess, postprocess,
                          ENCODER_LAYERS, DECODER_ARCHS, decoder_layers)

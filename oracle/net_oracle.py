@@ -155,7 +155,7 @@ def postprocess(image01):
 
 
 def stylize(content, style, weights, relu_targets, alpha=1.0, adain=False,
-            wct_mode='tf', return_levels=False):
+            wct_mode='tf', return_levels=False, swap5=False, ss_alpha=0.6, ss_patch_size=3, ss_stride=1):
     """One WCT.predict (wct.py:70-106) through the test-mode graph
     (model.py:33-94,123-176): ONE style pass with all taps; levels in
     `relu_targets` order; level i>0 encodes clip(previous decoded, 0, 1)
@@ -174,7 +174,9 @@ def stylize(content, style, weights, relu_targets, alpha=1.0, adain=False,
             x = np.clip(x, 0, 1)
         fc = encode(x, weights, [relu])[relu]
         fs = style_feats[relu]
-        if adain:
+        if swap5 and relu == 'relu5_1':          # tf.case priority swap5 > adain > wct (model.py:148-154)
+            t = wct_oracle.wct_style_swap(fc, fs, ss_alpha, ss_patch_size, ss_stride)[0]
+        elif adain:
             t = wct_oracle.adain(fc, fs, alpha)[0]
         elif wct_mode == 'tf':
             t = wct_oracle.wct_tf(fc, fs, alpha)[0]

@@ -154,3 +154,77 @@ def preserve_colors_np(style_rgb, content_rgb):
     """utils.py:87-90: CORAL on [0,1] images, clip, truncate to uint8."""
     coraled = coral_numpy(style_rgb / 255., content_rgb / 255.)
     return np.uint8(np.clip(coraled, 0, 1) * 255.)
+
+
+def style_swap(content, style, patch_size, stride):
+    """Patch swap, semantics of ops.py:220-278 (batch dim dropped: HxWxC in, HxWxC out).
+
+    * every patch_size^2 x C patch of `style` at `stride` (VALID) is a filter;
+    * the filters are L2-normalised with tf.nn.l2_normalize(..., dim=3) on the [p,p,C,P] tensor, i.e.
+      along the PATCH axis -- each filter element is divided by the norm of that element over all
+      patches (ops.py:233; epsilon 1e-12 under the square root) -- reproduced literally;
+    * correlation = VALID conv of `content` with the normalised filters at `stride`; argmax over patches
+      (first index on ties); the UN-normalised winning patch is pasted back (conv2d_transpose of the
+      one-hot map, ops.py:255-259) and overlaps are averaged by the coverage count (ops.py:262-276).
+    """
+    c = np.asarray(content, np.float32)
+    s = np.asarray(style, np.float32)
+    p, st = int(patch_size), int(stride)
+    hs, ws, ch = s.shape
+    rows, cols = (hs - p) // st + 1, (ws - p) // st + 1
+    patches = np.empty((rows * cols, p, p, ch), np.float32)
+    for r in range(rows):
+        for q in range(cols):
+            patches[r * cols + q] = s[r * st:r * st + p, q * st:q * st + p, :]
+    sq = np.sum(patches.astype(np.float32) ** 2, axis=0, dtype=np.float32)
+    normed = patches * (1.0 / np.sqrt(np.maximum(sq, np.float32(1e-12))))[None]
+    hc, wc, _ = c.shape
+    ho, wo = (hc - p) // st + 1, (wc - p) // st + 1
+    cols_c = np.empty((ho * wo, p * p * ch), np.float32)
+    for y in range(ho):
+        for x in range(wo):
+            cols_c[y * wo + x] = c[y * st:y * st + p, x * st:x * st + p, :].reshape(-1)
+    enc = cols_c @ normed.reshape(rows * cols, -1).T
+    arg = np.argmax(enc, axis=1)
+    hd, wd = (ho - 1) * st + p, (wo - 1) * st + p
+    dec = np.zeros((hd, wd, ch), np.float32)
+    cnt = np.zeros((hd, wd, 1), np.float32)
+    for y in range(ho):
+        for x in range(wo):
+            dec[y * st:y * st + p, x * st:x * st + p, :] += patches[arg[y * wo + x]]
+            cnt[y * st:y * st + p, x * st:x * st + p, :] += 1
+    return dec / cnt
+
+
+def wct_style_swap(content, style, alpha, patch_size=3, stride=1, eps=1e-8):
+    """ops.py:145-218: whiten content and style (S^-1/2, no eps in the gains; eps*I on the covariances),
+    style_swap on the whitened maps, colour with the style's S^1/2, add the style mean, blend with the
+    un-centred content (ops.py:210)."""
+    fc_full, cshape = _flatten_chw(np.asarray(content, np.float32))
+    fs_full, sshape = _flatten_chw(np.asarray(style, np.float32))
+    c = fc_full.shape[0]
+    eye = np.eye(c, dtype=np.float32)
+    mc = fc_full.mean(axis=1, keepdims=True)
+    fc = fc_full - mc
+    cov_c = np.dot(fc, fc.T) / np.float32(fc.shape[1] - 1.0) + eye * np.float32(eps)
+    ms = fs_full.mean(axis=1, keepdims=True)
+    fs = fs_full - ms
+    cov_s = np.dot(fs, fs.T) / np.float32(fs.shape[1] - 1.0) + eye * np.float32(eps)
+    uc, sc, _ = np.linalg.svd(cov_c)
+    us, ss, _ = np.linalg.svd(cov_s)
+    kc = int((sc > 1e-5).sum())
+    ks = int((ss > 1e-5).sum())
+    wc_mat = uc[:, :kc].dot(np.diag(sc[:kc] ** np.float32(-0.5))).dot(uc[:, :kc].T)
+    ws_mat = us[:, :ks].dot(np.diag(ss[:ks] ** np.float32(-0.5))).dot(us[:, :ks].T)
+    whiten_c = _unflatten(wc_mat.dot(fc), cshape)[0]
+    whiten_s = _unflatten(ws_mat.dot(fs), sshape)[0]
+    swapped = style_swap(whiten_c, whiten_s, patch_size, stride)
+    hcw = cshape[0] * cshape[1]
+    if swapped.shape[0] * swapped.shape[1] != hcw:
+        raise ValueError('style-swap output %s does not match the content map %s: pre-size the content '
+                         '(utils.swap_filter_fit, wct.py:84-90)' % (swapped.shape, cshape))
+    ssf = swapped.reshape(hcw, c).T
+    col = us[:, :ks].dot(np.diag(ss[:ks] ** np.float32(0.5))).dot(us[:, :ks].T)
+    fcs = col.dot(ssf) + ms
+    blended = np.float32(alpha) * fcs + np.float32(1 - alpha) * (fc + mc)
+    return np.float32(_unflatten(blended, cshape))

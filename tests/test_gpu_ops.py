@@ -216,3 +216,25 @@ def test_coral_matches_reference(ctx):
     want = oracle.preserve_colors_np(s, t)
     diff = np.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+@pytest.mark.parametrize('c,hc,wc,hs,ws,p,st', [
+    (64, 12, 12, 10, 14, 3, 1),
+    (512, 32, 32, 32, 32, 3, 1),       # relu5_1 of a 512x512 pair
+    (128, 9, 11, 8, 8, 1, 1),
+    (64, 11, 13, 9, 9, 3, 2),          # stride 2 on sizes that survive the round trip
+])
+def test_style_swap(ctx, c, hc, wc, hs, ws, p, st):
+    from wct_tf_amd import ops
+    fc = synthetic_features(90 + c, c, hc, wc, 1.5)
+    fs = synthetic_features(95 + c, c, hs, ws, 1.5)
+    want = oracle.wct_style_swap(fc, fs, 0.6, p, st)
+    got = ops.wct_style_swap(fc, fs, 0.6, p, st, ctx=ctx)
+    e = rel_err(got, want)
+    # a near-tie in the patch correlation may legitimately pick another patch: count differing pixels
+    diff_px = (np.abs(got - want).max(-1) > 1e-3 * np.abs(want).max()).mean()
+    print('style_swap C=%d %dx%d p=%d st=%d: rel %.2e, pixels differing %.4f' % (c, hc, wc, p, st, e, diff_px))
+    assert got.shape == want.shape
+    assert e < 1e-3 or diff_px < 0.01
+    with pytest.raises(Exception):
+        ops.wct_style_swap(synthetic_features(1, 64, 12, 12), fs[:, :9, :9, :64] if c == 64 else synthetic_features(2, 64, 9, 9), 0.6, 3, 2, ctx=ctx)   # 12 does not survive stride 2

@@ -143,8 +143,6 @@ def test_wct_facade_and_batch(ctx, weights):
     assert np.array_equal(out, ctx.stylize(c, s, targets, alpha=0.8))
     with pytest.raises(Exception):
         WCT(checkpoints=['/nonexistent'], relu_targets=targets, vgg_path='/nonexistent.npz')
-    with pytest.raises(NotImplementedError):
-        model.predict(c, s, swap5=True)
     # batched device-resident entry point == per-pair calls, bit for bit
     B = 3
     cs = np.stack([synthetic_image(1000 + i, 48, 48) for i in range(B)])
@@ -231,3 +229,28 @@ def test_full_size_properties_512(ctx, weights):
         err = np.linalg.norm(cov_o - cov_s) / np.linalg.norm(cov_s)
         print(relu, 'sweeps', sweeps, 'cov err %.2e' % err)
         assert err < 5e-3
+
+
+def test_swap5_pipeline(ctx, weights):
+    """--swap5: style-swap at relu5_1 (priority over adain), WCT below.  The fused call must equal the
+    GPU ops chained by hand; the relu5_1 op is checked against the oracle on the oracle's features."""
+    from wct_tf_amd import _lib
+    targets = ['relu5_1', 'relu2_1']
+    c = synthetic_image(1003, 128, 96)
+    s = synthetic_image(2003, 112, 112)
+    _, levels = oracle.stylize(c, s, weights, targets, alpha=0.8, swap5=True, ss_alpha=0.6, return_levels=True)
+    fc, fs, t, _ = levels[0]
+    got_t = ctx.style_swap(fc, fs, 0.6)
+    e = rel_err(got_t, t)
+    print('swap5 relu5_1 op on oracle features: rel %.2e' % e, fc.shape, fs.shape)
+    assert e < 1e-3
+    ctx.set_style_swap(0.6, 3, 1)
+    got = ctx.stylize(c, s, targets, alpha=0.8, swap5=True, adain=True)       # swap5 wins at relu5_1, adain below
+    x = np.float32(c / 255.)
+    s01 = np.float32(s / 255.)
+    t5 = ctx.style_swap(ctx.encode(x, 'relu5_1'), ctx.encode(s01, 'relu5_1'), 0.6)
+    x = np.clip(ctx.decode(t5, 'relu5_1'), 0, 1)
+    from wct_tf_amd import ops
+    t2 = ops.adain(ctx.encode(x, 'relu2_1'), ctx.encode(s01, 'relu2_1'), 0.8, ctx=ctx)[0]
+    x = ctx.decode(t2, 'relu2_1')
+    assert np.array_equal(got, np.uint8(np.clip(x, 0, 1) * 255))

@@ -155,3 +155,38 @@ def test_five_level_chain_is_chaotic_on_random_weights():
     b = oracle.stylize(c2, s, w, targets, alpha=0.8)
     d = np.abs(a.astype(int) - b.astype(int))
     assert d.mean() > 2.0, d.mean()
+
+
+def test_style_swap_matches_torch():
+    """style_swap restatement vs an independent torch-CPU build of the same graph (conv2d with the
+    patch filters, argmax, one-hot, conv_transpose2d, coverage count) -- the reference runs this in TF."""
+    rng = np.random.default_rng(2)
+    for (hc, wc, hs, ws, ch, p, st) in [(9, 8, 7, 10, 6, 3, 1), (11, 11, 9, 9, 4, 3, 2), (6, 6, 6, 6, 5, 1, 1)]:
+        c = rng.standard_normal((hc, wc, ch)).astype(np.float32)
+        s = rng.standard_normal((hs, ws, ch)).astype(np.float32)
+        got = oracle.style_swap(c, s, p, st)
+        ct = torch.from_numpy(c.transpose(2, 0, 1)[None])
+        stt = torch.from_numpy(s.transpose(2, 0, 1)[None])
+        patches = F.unfold(stt, p, stride=st)[0].T.reshape(-1, ch, p, p)           # [P, C, p, p]
+        norm = patches / torch.sqrt(torch.clamp((patches ** 2).sum(0, keepdim=True), min=1e-12))
+        enc = F.conv2d(ct, norm, stride=st)
+        oh = F.one_hot(enc.argmax(1), enc.shape[1]).permute(0, 3, 1, 2).float()
+        dec = F.conv_transpose2d(oh, patches, stride=st)
+        cnt = F.conv_transpose2d(oh.sum(1, keepdim=True), torch.ones(1, 1, p, p), stride=st)
+        want = (dec / cnt)[0].permute(1, 2, 0).numpy()
+        assert got.shape == want.shape
+        assert rel_err(got, want) < 1e-5, (hc, wc, p, st)
+
+
+def test_wct_style_swap_properties():
+    fc = synthetic_features(7, 16, 10, 10, 1.0)
+    fs = synthetic_features(8, 16, 9, 12, 1.0)
+    out = oracle.wct_style_swap(fc, fs, 0.6)
+    assert out.shape == fc.shape and out.dtype == np.float32
+    assert rel_err(oracle.wct_style_swap(fc, fs, 0.0), fc) < 1e-6        # alpha = 0 returns the content
+    # 1x1 patches, stride 1: every whitened content vector is replaced by a whitened style vector, so the
+    # coloured result at alpha = 1 consists of actual style feature vectors
+    out1 = oracle.wct_style_swap(fc, fs, 1.0, patch_size=1)[0].reshape(-1, 16)
+    s_flat = fs[0].reshape(-1, 16)
+    d = np.abs(out1[:, None, :] - s_flat[None, :, :]).max(-1).min(-1)
+    assert d.max() < 2e-3 * np.abs(s_flat).max()

@@ -29,6 +29,8 @@ SIGNATURES = [
     ('wct_set_decoder', C.c_int, [_P, C.c_int, C.POINTER(_F), C.POINTER(_F), C.c_int]),
     ('wct_transform', C.c_int, [_P, _F, C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _F, _I]),
     ('wct_adain', C.c_int, [_P, _F, C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_float, _F]),
+    ('wct_style_swap', C.c_int, [_P, _F, C.c_int, C.c_int, _F, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float, _F]),
+    ('wct_set_style_swap', C.c_int, [_P, C.c_float, C.c_int, C.c_int]),
     ('wct_eigh', C.c_int, [_P, _F, C.c_int, C.c_int, _F, _F, _I]),
     ('wct_conv3x3', C.c_int, [_P, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.c_int, C.c_int, C.c_int, _F]),
     ('wct_maxpool', C.c_int, [_P, _F, C.c_int, C.c_int, C.c_int, _F]),
@@ -51,7 +53,7 @@ SIGNATURES = [
 ]
 
 WCT_NP, WCT_TF = 0, 1
-FLAG_ADAIN, FLAG_MODE_NP = 1, 2
+FLAG_ADAIN, FLAG_MODE_NP, FLAG_SWAP5 = 1, 2, 4
 PROF_CLASSES = ['conv3x3', 'conv_first', 'conv_last', 'pool', 'wct_cov', 'jacobi', 'wct_apply', 'other']
 
 _lib = None

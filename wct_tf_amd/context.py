@@ -101,6 +101,18 @@ class Context(object):
                                  float(alpha), float(epsilon), fptr(out)))
         return out
 
+    def style_swap(self, content, style, alpha, patch_size=3, stride=1, eps=-1.0):
+        """content [hc][wc][C], style [hs][ws][C] float32 -> [hc][wc][C] (ops.py:145-278)"""
+        c = f32(content)
+        s = f32(style)
+        out = np.empty_like(c)
+        check(self.lib.wct_style_swap(self.h, fptr(c), c.shape[0], c.shape[1], fptr(s), s.shape[0], s.shape[1],
+                                      c.shape[2], float(alpha), int(patch_size), int(stride), float(eps), fptr(out)))
+        return out
+
+    def set_style_swap(self, ss_alpha=0.6, patch_size=3, stride=1):
+        check(self.lib.wct_set_style_swap(self.h, float(ss_alpha), int(patch_size), int(stride)))
+
     def eigh(self, mats, return_sweeps=False):
         a = f32(mats)
         if a.ndim == 2:
@@ -177,14 +189,15 @@ class Context(object):
         check(self.lib.wct_output_size(hc, wc, arr, len(lv), C.byref(ho), C.byref(wo)))
         return ho.value, wo.value
 
-    def stylize(self, content_u8, style_u8, relu_targets, alpha=1.0, adain=False, wct_mode='tf'):
+    def stylize(self, content_u8, style_u8, relu_targets, alpha=1.0, adain=False, wct_mode='tf', swap5=False):
         c = u8(content_u8)
         s = u8(style_u8)
         lv = _levels(relu_targets)
         arr = (C.c_int * len(lv))(*lv)
         ho, wo = self.output_size(c.shape[0], c.shape[1], lv)
         out = np.empty((ho, wo, 3), np.uint8)
-        flags = (_lib.FLAG_ADAIN if adain else 0) | (_lib.FLAG_MODE_NP if wct_mode == 'np' else 0)
+        flags = (_lib.FLAG_ADAIN if adain else 0) | (_lib.FLAG_MODE_NP if wct_mode == 'np' else 0) | \
+            (_lib.FLAG_SWAP5 if swap5 else 0)
         check(self.lib.wct_stylize(self.h, c.ctypes.data_as(_lib._U8), c.shape[0], c.shape[1],
                                    s.ctypes.data_as(_lib._U8), s.shape[0], s.shape[1], arr, len(lv),
                                    float(alpha), flags, out.ctypes.data_as(_lib._U8)))

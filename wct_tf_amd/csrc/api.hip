@@ -60,6 +60,8 @@ struct wct_ctx {
   ConvLayer enc[12];               // conv1_2 .. conv5_1
   Decoder dec[6];
   DevBuf act[2], feat_c, feat_s[6], img_c, img_s, img_t[2], wct_out, wct_ws, stage[4];
+  float ss_alpha = 0.6f;           // style-swap settings (stylize.py:34-37 defaults)
+  int ss_patch = 3, ss_stride = 1;
   bool prof = false;
   std::vector<ProfRec> recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
@@ -509,6 +511,27 @@ extern "C" int wct_adain(wct_ctx* c, const float* content, int Nc, const float* 
   return fetch(c, out, c->stage[2].p, (size_t)Nc * C * 4);
 }
 
+extern "C" int wct_set_style_swap(wct_ctx* c, float ss_alpha, int patch_size, int stride) {
+  ARG_CHECK(c && patch_size >= 1 && stride >= 1);
+  c->ss_alpha = ss_alpha; c->ss_patch = patch_size; c->ss_stride = stride;
+  return WCT_OK;
+}
+
+extern "C" int wct_style_swap(wct_ctx* c, const float* content, int hc, int wc, const float* style, int hs, int ws,
+                              int C, float alpha, int patch_size, int stride, float eps, float* out) {
+  ARG_CHECK(c && content && style && out && hc > 0 && wc > 0 && hs > 0 && ws > 0);
+  HIP_TRY(hipSetDevice(c->device));
+  void *dc, *ds;
+  TRY(stage_in(c, 0, content, (size_t)hc * wc * C * 4, &dc));
+  TRY(stage_in(c, 1, style, (size_t)hs * ws * C * 4, &ds));
+  TRY(ensure(c, c->stage[2], (size_t)hc * wc * C * 4));
+  ARG_CHECK(patch_size >= 1 && stride >= 1 && hc >= patch_size && wc >= patch_size && hs >= patch_size && ws >= patch_size);
+  TRY(ensure(c, c->wct_ws, style_swap_workspace_bytes(C, hc, wc, hs, ws, patch_size, stride)));
+  TRY(launch_style_swap((float*)dc, hc, wc, (float*)ds, hs, ws, C, alpha, patch_size, stride, eps, nullptr,
+                        (float*)c->stage[2].p, c->wct_ws.p, c->wct_ws.cap, c->stream));
+  return fetch(c, out, c->stage[2].p, (size_t)hc * wc * C * 4);
+}
+
 __global__ void extract_diag_kernel(const float* A, float* d, int C) {
   const int m = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < C) d[m * C + k] = A[(size_t)m * C * C + (size_t)k * C + k];
@@ -699,6 +722,17 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
     // level i>0 encodes clip(previous decoded, 0, 1) (model.py:86): the clamp is in the conv1_1 loader
     TRY(run_encoder(c, cur, B, H, W, i > 0, l, ctaps));
     TRY(ensure(c, c->wct_out, (size_t)B * h * w * C * 2));
+    if (l == 5 && (flags & WCT_FLAG_SWAP5)) {
+      // tf.case priority at relu5_1: swap5 > adain > wct (model.py:148-154); pairs one at a time
+      ARG_CHECK(h >= c->ss_patch && w >= c->ss_patch && hs >= c->ss_patch && ws >= c->ss_patch);
+      TRY(ensure(c, c->wct_ws, style_swap_workspace_bytes(C, h, w, hs, ws, c->ss_patch, c->ss_stride)));
+      ProfScope ps(c, 7, 0, 0);
+      for (int b = 0; b < B; ++b)
+        TRY(launch_style_swap((float*)c->feat_c.p + (size_t)b * h * w * C, h, w,
+                              (float*)c->feat_s[l].p + (size_t)b * hs * ws * C, hs, ws, C, c->ss_alpha, c->ss_patch,
+                              c->ss_stride, -1.f, (half_t*)c->wct_out.p + (size_t)b * h * w * C, nullptr,
+                              c->wct_ws.p, c->wct_ws.cap, c->stream));
+    } else
     TRY(run_transform(c, (float*)c->feat_c.p, h * w, (float*)c->feat_s[l].p, hs * ws, C, B, alpha, flags, -1.f,
                       (half_t*)c->wct_out.p, nullptr, nullptr));
     const int scale = 1 << (l - 1);

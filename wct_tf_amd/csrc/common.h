@@ -100,6 +100,12 @@ int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace,
                        size_t workspace_bytes, int* sweeps_done_dev, hipStream_t s);
 size_t jacobi_workspace_bytes(int C, int nmat);
 
+// Style-swap at relu5_1 (ops.py:145-278): one pair, content [hc*wc][C], style [hs*ws][C] fp32.
+size_t style_swap_workspace_bytes(int C, int hc, int wc, int hs, int ws, int patch, int stride);
+int launch_style_swap(const float* content, int hc, int wc, const float* style, int hs, int ws, int C,
+                      float alpha, int patch, int stride, float eps, half_t* out16, float* out32,
+                      void* workspace, size_t workspace_bytes, hipStream_t s);
+
 // ---- coral.hip ------------------------------------------------------------
 struct CoralApplyArgs {
   double M[9], src_mean[3], src_std[3], tgt_mean[3], tgt_std[3];

@@ -955,3 +955,214 @@ int launch_adain(const float* content, int Nc, const float* style, int Ns, int C
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Style-swap at relu5_1 (ops.py:145-278, `--swap5`): whiten content and style, replace every
+// content patch by its best-correlated (un-normalised) style patch, colour with the style.
+// One content/style pair per call; the batch loop is in api.hip.
+// ---------------------------------------------------------------------------
+// gains for the three spectral matrices: content whitening, style whitening, style colouring
+__global__ void swap_gain_kernel(const float* A, float* d_cw, float* d_sw, float* d_sc, int C) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= C) return;
+  const float lc = A[(size_t)k * C + k], ls = A[(size_t)C * C + (size_t)k * C + k];
+  d_cw[k] = lc > 1e-5f ? 1.f / sqrtf(lc) : 0.f;        // ops.py:187-189
+  d_sw[k] = ls > 1e-5f ? 1.f / sqrtf(ls) : 0.f;        // ops.py:197-198
+  d_sc[k] = ls > 1e-5f ? sqrtf(ls) : 0.f;              // ops.py:208-209
+}
+
+// dst[m][(i*p + j)*C + c] = src[(y*st + i)][(x*st + j)][c],  m = y*wo + x   (tf.extract_image_patches, VALID)
+__global__ void im2col_kernel(const float* src, float* dst, int w, int C, int p, int st, int ho, int wo) {
+  const int c4n = C / 4;
+  const size_t total = (size_t)ho * wo * p * p * c4n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    size_t t = e / c4n;
+    const int j = (int)(t % p); t /= p;
+    const int i = (int)(t % p); t /= p;
+    const int x = (int)(t % wo), y = (int)(t / wo);
+    reinterpret_cast<f32x4*>(dst)[e] =
+        *reinterpret_cast<const f32x4*>(src + ((size_t)(y * st + i) * w + (x * st + j)) * C + c4 * 4);
+  }
+}
+
+// inv[k] = rsqrt(max(sum_n B[n][k]^2, 1e-12))   -- tf.nn.l2_normalize(dim=3): over the PATCH axis (ops.py:233)
+__global__ void patch_axis_inv_norm_kernel(const float* B, float* inv, int n, int K) {
+  const int k4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k4 * 4 >= K) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < n; ++r) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(B + (size_t)r * K + k4 * 4);
+    s += v * v;
+  }
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = 1.f / sqrtf(fmaxf(s[j], 1e-12f));
+  *reinterpret_cast<f32x4*>(inv + k4 * 4) = o;
+}
+
+// idx[m] = first argmax_n E[m][n]; one wave per row
+__global__ __launch_bounds__(64) void row_argmax_kernel(const float* E, int* idx, int n) {
+  const int m = blockIdx.x, lane = threadIdx.x;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int j = lane; j < n; j += 64) {
+    const float v = E[(size_t)m * n + j];
+    if (v > best) { best = v; bi = j; }          // ascending j per lane keeps the first maximum
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) idx[m] = bi;
+}
+
+// overlap-add of the winning patches divided by the coverage count (ops.py:255-276), as a gather
+__global__ void swap_reconstruct_kernel(const float* patches /* [Pn][p*p*C] */, const int* idx, float* out,
+                                        int h, int w, int C, int p, int st, int ho, int wo) {
+  const int c4n = C / 4;
+  const size_t total = (size_t)h * w * c4n;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % c4n);
+    const size_t pix = e / c4n;
+    const int x = (int)(pix % w), y = (int)(pix / w);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float cnt = 0.f;
+    for (int i = 0; i < p; ++i) {
+      const int yy = y - i;
+      if (yy < 0 || yy % st) continue;
+      const int py = yy / st;
+      if (py >= ho) continue;
+      for (int j = 0; j < p; ++j) {
+        const int xx = x - j;
+        if (xx < 0 || xx % st) continue;
+        const int px = xx / st;
+        if (px >= wo) continue;
+        const int n = idx[py * wo + px];
+        acc += *reinterpret_cast<const f32x4*>(patches + ((size_t)n * p * p + i * p + j) * C + c4 * 4);
+        cnt += 1.f;
+      }
+    }
+    reinterpret_cast<f32x4*>(out)[e] = acc / cnt;
+  }
+}
+
+// out = alpha * (col + ms) + (1 - alpha) * x      (ops.py:210-213)
+__global__ void swap_blend_kernel(const float* col, const float* x, const float* ms, size_t n4, int C, float alpha,
+                                  half_t* out16, float* out32) {
+  const int cq = C / 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cq) * 4;
+    const f32x4 a = reinterpret_cast<const f32x4*>(col)[i], b = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 m = *reinterpret_cast<const f32x4*>(ms + c);
+    const f32x4 o = alpha * (a + m) + (1.f - alpha) * b;
+    if (out32) reinterpret_cast<f32x4*>(out32)[i] = o;
+    if (out16) {
+      half4 h;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = (half_t)o[j];
+      reinterpret_cast<half4*>(out16)[i] = h;
+    }
+  }
+}
+
+struct SwapCarve {
+  float *d3, *Wc, *Ws, *Ac, *Bs, *inv, *E, *ss, *col;
+  int* idx;
+  size_t total;
+};
+
+static SwapCarve swap_carve(void* base, int C, int hc, int wc, int hs, int ws, int p, int st) {
+  SwapCarve w;
+  const size_t K = (size_t)p * p * C;
+  const size_t Mo = (size_t)((hc - p) / st + 1) * ((wc - p) / st + 1);
+  const size_t Pn = (size_t)((hs - p) / st + 1) * ((ws - p) / st + 1);
+  size_t off = 0;
+  char* b = reinterpret_cast<char*>(base);
+  auto take = [&](size_t bytes) { void* q = b ? b + off : nullptr; off += align_up(bytes); return q; };
+  w.d3 = (float*)take(3 * (size_t)C * 4);
+  w.Wc = (float*)take((size_t)hc * wc * C * 4);
+  w.Ws = (float*)take((size_t)hs * ws * C * 4);
+  w.Ac = (float*)take(Mo * K * 4);
+  w.Bs = (float*)take(Pn * K * 4);
+  w.inv = (float*)take(K * 4);
+  w.E = (float*)take(Mo * Pn * 4);
+  w.idx = (int*)take(Mo * 4);
+  w.ss = (float*)take((size_t)hc * wc * C * 4);
+  w.col = (float*)take((size_t)hc * wc * C * 4);
+  w.total = off;
+  return w;
+}
+
+size_t style_swap_workspace_bytes(int C, int hc, int wc, int hs, int ws, int p, int st) {
+  return wct_workspace_bytes(C, hc * wc, hs * ws, 1) + swap_carve(nullptr, C, hc, wc, hs, ws, p, st).total + 1024;
+}
+
+static inline unsigned ew_grid(size_t n) { size_t g = (n + 255) / 256; return (unsigned)(g > 4096 ? 4096 : (g ? g : 1)); }
+
+int launch_style_swap(const float* content, int hc, int wc, const float* style, int hs, int ws, int C,
+                      float alpha, int patch, int stride, float eps, half_t* out16, float* out32,
+                      void* workspace, size_t workspace_bytes, hipStream_t s) {
+  ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && patch >= 1 && stride >= 1);
+  ARG_CHECK(hc >= patch && wc >= patch && hs >= patch && ws >= patch);
+  const int ho = (hc - patch) / stride + 1, wo = (wc - patch) / stride + 1;
+  const int rows = (hs - patch) / stride + 1, cols = (ws - patch) / stride + 1;
+  if ((ho - 1) * stride + patch != hc || (wo - 1) * stride + patch != wc) {
+    wct_set_error("style-swap with patch %d stride %d maps a %dx%d feature map to %dx%d: pre-size the content "
+                  "(swap_filter_fit / center_crop_to, wct.py:84-90)", patch, stride, hc, wc,
+                  (ho - 1) * stride + patch, (wo - 1) * stride + patch);
+    return WCT_ERR_ARG;
+  }
+  const int Nc = hc * wc, Ns = hs * ws, Mo = ho * wo, Pn = rows * cols, K = patch * patch * C;
+  const size_t wct_bytes = align_up(wct_workspace_bytes(C, Nc, Ns, 1));
+  ARG_CHECK(workspace_bytes >= style_swap_workspace_bytes(C, hc, wc, hs, ws, patch, stride));
+  WctCarve w = carve(workspace, C, Nc, Ns, 1);
+  SwapCarve sw = swap_carve((char*)workspace + wct_bytes, C, hc, wc, hs, ws, patch, stride);
+  int rc;
+  // statistics, covariances (+eps I), eigendecompositions: the same stages as wct_tf
+  if ((rc = launch_wct(content, Nc, style, Ns, C, 1, alpha, WCT_MODE_TF, eps, nullptr, nullptr, workspace, wct_bytes,
+                       nullptr, WCT_STAGE_COV | WCT_STAGE_EIG, s, nullptr, 0, nullptr, nullptr))) return rc;
+  const size_t cc = (size_t)C * C;
+  float *d_cw = sw.d3, *d_sw = sw.d3 + C, *d_sc = sw.d3 + 2 * C;
+  hipLaunchKernelGGL(swap_gain_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, w.A, d_cw, d_sw, d_sc, C);
+  auto spectral = [&](const float* V, const float* d, float* out) {     // out = V diag(d) V^T
+    GemmArgs g = {};
+    g.A = V; g.lda = C; g.a_kmajor = 0; g.a_scale_k = d; g.B = V; g.ldb = C; g.b_kmajor = 0;
+    g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = out; g.ldo = C;
+    return launch_gemm(g, 1, 1, s);
+  };
+  if ((rc = spectral(w.V, d_cw, w.Tw))) return rc;              // content whitening
+  if ((rc = spectral(w.V + cc, d_sw, w.Tcs))) return rc;        // style whitening
+  if ((rc = spectral(w.V + cc, d_sc, w.T))) return rc;          // style colouring
+  auto apply = [&](const float* X, int N, const float* mean, const float* T, float* out) {   // out = (X - mean) T^T
+    GemmArgs g = {};
+    g.A = X; g.lda = C; g.a_kmajor = 0; g.a_sub_k = mean; g.B = T; g.ldb = C; g.b_kmajor = 0;
+    g.M = N; g.N = C; g.K = C; g.ksplit = C; g.out32 = out; g.ldo = C;
+    return launch_gemm(g, 1, 1, s);
+  };
+  if ((rc = apply(content, Nc, w.mean, w.Tw, sw.Wc))) return rc;
+  if ((rc = apply(style, Ns, w.mean + C, w.Tcs, sw.Ws))) return rc;
+  hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid((size_t)Mo * K / 4)), dim3(256), 0, s, sw.Wc, sw.Ac, wc, C, patch, stride, ho, wo);
+  hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid((size_t)Pn * K / 4)), dim3(256), 0, s, sw.Ws, sw.Bs, ws, C, patch, stride, rows, cols);
+  hipLaunchKernelGGL(patch_axis_inv_norm_kernel, dim3(cdiv(K / 4, 64)), dim3(64), 0, s, sw.Bs, sw.inv, Pn, K);
+  {  // E[m][n] = sum_k Ac[m][k] inv[k] Bs[n][k]
+    GemmArgs g = {};
+    g.A = sw.Ac; g.lda = K; g.a_kmajor = 0; g.a_scale_k = sw.inv; g.B = sw.Bs; g.ldb = K; g.b_kmajor = 0;
+    g.M = Mo; g.N = Pn; g.K = K; g.ksplit = K; g.out32 = sw.E; g.ldo = Pn;
+    if ((rc = launch_gemm(g, 1, 1, s))) return rc;
+  }
+  hipLaunchKernelGGL(row_argmax_kernel, dim3(Mo), dim3(64), 0, s, sw.E, sw.idx, Pn);
+  hipLaunchKernelGGL(swap_reconstruct_kernel, dim3(ew_grid((size_t)Nc * C / 4)), dim3(256), 0, s, sw.Bs, sw.idx, sw.ss,
+                     hc, wc, C, patch, stride, ho, wo);
+  {  // col = ss . Tcol^T
+    GemmArgs g = {};
+    g.A = sw.ss; g.lda = C; g.a_kmajor = 0; g.B = w.T; g.ldb = C; g.b_kmajor = 0;
+    g.M = Nc; g.N = C; g.K = C; g.ksplit = C; g.out32 = sw.col; g.ldo = C;
+    if ((rc = launch_gemm(g, 1, 1, s))) return rc;
+  }
+  hipLaunchKernelGGL(swap_blend_kernel, dim3(ew_grid((size_t)Nc * C / 4)), dim3(256), 0, s, sw.col, content, w.mean + C,
+                     (size_t)Nc * C / 4, C, alpha, out16, out32);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}

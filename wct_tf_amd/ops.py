@@ -52,6 +52,16 @@ def adain(content_features, style_features, alpha, epsilon=1e-5, ctx=None):
     return out.reshape(1, h, w, c)
 
 
+def wct_style_swap(content, style, alpha, patch_size=3, stride=1, eps=1e-8, ctx=None):
+    """ops.py:145: 1xHxWxC content/style encodings -> float32 1xHxWxC"""
+    ctx = ctx or default_context()
+    c = np.squeeze(np.asarray(content, np.float32))
+    s = np.squeeze(np.asarray(style, np.float32))
+    if c.ndim != 3 or s.ndim != 3:
+        raise ValueError('style swap needs single 1xHxWxC feature maps')
+    return ctx.style_swap(c, s, alpha, patch_size, stride, eps)[None]
+
+
 def _moments_from_sums(sums, npix):
     """mean / population std / (Xn Xn^T + I) of img/255 from the exact integer moments."""
     s1 = sums[:3] / 255.0

@@ -1,7 +1,7 @@
 """`python -m wct_tf_amd.stylize ...`: the reference's stylize.py CLI (stylize.py:14-126) on the MI355X
 path.  Same flags and output naming ({content}_{style}{ext}); `--checkpoints` / `--vgg-path` take .npz
 files written by wct_tf_amd.weights.save_weights (see wct.py), or `--synthetic-weights SEED` stands in
-for the absent pre-trained files.  `--swap5` (style-swap) is not built on this path."""
+for the absent pre-trained files."""
 from __future__ import division, print_function
 
 import argparse
@@ -32,7 +32,7 @@ def build_parser():
     parser.add_argument('--alpha', type=float, help="Alpha blend value", default=1)
     parser.add_argument('--concat', action='store_true', help="Concatenate style image and stylized output", default=False)
     parser.add_argument('--adain', action='store_true', help="Use AdaIN instead of WCT", default=False)
-    # Style swap args (accepted for CLI compatibility; --swap5 raises NotImplementedError in predict)
+    # Style swap args
     parser.add_argument('--swap5', action='store_true', help="Swap style on layer relu5_1", default=False)
     parser.add_argument('--ss-alpha', type=float, help="Style swap alpha blend", default=0.6)
     parser.add_argument('--ss-patch-size', type=int, help="Style swap patch size", default=3)

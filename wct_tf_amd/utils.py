@@ -27,6 +27,34 @@ def _imresize(img, shape_hw):
     return np.asarray(Image.fromarray(np.uint8(img)).resize((w, h), Image.BILINEAR))
 
 
+def center_crop_to(img, H_target, W_target):
+    '''Center crop a rectangle of given dimensions and resize if necessary (utils.py:40-53)'''
+    height, width = img.shape[0], img.shape[1]
+    if height < H_target or width < W_target:
+        rat = max(H_target / height, W_target / width)
+        img = _imresize(img, (int(round(height * rat)), int(round(width * rat))))
+        height, width = img.shape[0], img.shape[1]
+    h_off = (height - H_target) // 2
+    w_off = (width - W_target) // 2
+    return img[h_off:h_off + H_target, w_off:w_off + W_target]
+
+
+def swap_filter_fit(H, W, patch_size, stride, n_pools=4):
+    '''Style swap may not output same size encoding if filter size > 1, calculate a new size to avoid
+       this (utils.py:115-138): returns (should_refit, H_out, W_out)'''
+    H_pool_out, W_pool_out = H, W
+    for _ in range(n_pools):
+        H_pool_out, W_pool_out = (H_pool_out + 1) // 2, (W_pool_out + 1) // 2
+    H_conv_out = (H_pool_out - patch_size) // stride + 1
+    W_conv_out = (W_pool_out - patch_size) // stride + 1
+    H_deconv_out = (H_conv_out - 1) * stride + patch_size
+    W_deconv_out = (W_conv_out - 1) * stride + patch_size
+    H_out = H_deconv_out * 2 ** n_pools
+    W_out = W_deconv_out * 2 ** n_pools
+    should_refit = (H_pool_out != H_deconv_out) or (W_pool_out != W_deconv_out)
+    return should_refit, H_out, W_out
+
+
 def resize_to(img, resize=512):
     '''Resize short side to target size and preserve aspect ratio (utils.py:55-67)'''
     height, width = img.shape[0], img.shape[1]

@@ -83,14 +83,19 @@ class WCT(object):
         '''Stylize a single content/style pair; arrays in [0,255], returns uint8 HxWx3.
            The /255 preprocess and the clip*255 postprocess run inside the library
            (fused at the ends of the kernel chain).'''
-        if swap5:
-            # style-swap (ops.py:145-278) is SURVEY 8f "next", not on this path yet
-            raise NotImplementedError('swap5 (style-swap) is not built on the MI355X path')
         content = np.asarray(content)
         style = np.asarray(style)
+        # If doing style swap and stride > 1 the content might need to be resized for the filter to fit
+        if swap5 is True and self.ss_stride != 1:
+            from .utils import swap_filter_fit, center_crop_to
+            should_refit, H, W = swap_filter_fit(content.shape[0], content.shape[1], self.ss_patch_size, self.ss_stride)
+            if should_refit:
+                content = center_crop_to(content, H, W)
+        if swap5:
+            self.sess.set_style_swap(ss_alpha, self.ss_patch_size, self.ss_stride)
         if content.dtype != np.uint8:
             content = np.uint8(np.clip(content, 0, 255))
         if style.dtype != np.uint8:
             style = np.uint8(np.clip(style, 0, 255))
         return self.sess.stylize(content, style, self.relu_targets, alpha=alpha, adain=adain,
-                                 wct_mode=self.wct_mode)
+                                 wct_mode=self.wct_mode, swap5=bool(swap5))
