@@ -571,7 +571,7 @@ struct JacobiGroup {
 };
 
 static JacobiState* jacobi_host_flags() {
-  static JacobiState* h = nullptr;            // pinned, 4 groups x 64 matrices
+  static thread_local JacobiState* h = nullptr;   // pinned, 4 groups x 64 matrices; one per host thread (= per ctx user)
   if (!h && hipHostMalloc((void**)&h, 4 * 64 * sizeof(JacobiState)) != hipSuccess) h = nullptr;
   return h;
 }
