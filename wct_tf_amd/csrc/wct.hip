@@ -854,8 +854,11 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       // The eigensolver alternates a latency-bound kernel on a few workgroups (pair problems) with a
       // chip-wide tile update.  Splitting the batch into groups on separate streams lets one group's
       // pair problems hide under the other groups' tile updates.
+      // measured: splitting pays while a group still has few matrices (batch 8: 4 groups 22.3 ms vs 1 group
+      // 23.8 ms); at batch 16 one group is best (22.8 vs 24.1 ms with 4: twice the launches, no idle CUs to fill)
       int ngrp = nside + 1;
       if (ngrp > P) ngrp = P;
+      if (ngrp > 16 / P) ngrp = 16 / P < 1 ? 1 : 16 / P;
       if (ngrp > 4) ngrp = 4;
       JacobiGroup grp[4];
       HIP_TRY(hipEventRecord(ev_fork, s));
