@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 LEVELS = ['relu5_1', 'relu4_1', 'relu3_1', 'relu2_1', 'relu1_1']
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 HBM_PEAK_GBS = 8000.0
-PMC_BATCH = 16                            # batch the committed PMC passes were collected at
+PMC_BATCH = 32                            # batch the committed PMC passes were collected at
 
 
 def conv_flops_per_frame(size):
@@ -87,7 +87,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=16, help='independent content/style pairs per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='independent content/style pairs per GPU per step')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--alpha', type=float, default=0.8)
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
     const size_t pix = out_base + (size_t)oy * p.W + ox;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      unsigned pk[4][2];                      // fp16 x4 of each register quad, packed
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int co = n0 + (wn * NT + nt) * 32 + 8 * rq + 4 * kgrp;
@@ -233,14 +234,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
           float t = acc[nt][mt][rq * 4 + j] + bv[j];
           v[j] = p.relu ? fmaxf(t, 0.f) : t;
         }
-        if (inside) {
-          if (p.y16) {
-            half4 h;
+        if (inside && p.y32) *reinterpret_cast<f32x4*>(p.y32 + pix * p.Cout + co) = v;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 lo = {(half_t)v[0], (half_t)v[1]}, hi = {(half_t)v[2], (half_t)v[3]};
+        pk[rq][0] = __builtin_bit_cast(unsigned, lo);
+        pk[rq][1] = __builtin_bit_cast(unsigned, hi);
+      }
+      if (p.y16) {
+        // a lane holds channels 8rq+4kgrp..+3 of its pixel: the two half-waves own interleaved 8-byte
+        // pieces.  One v_permlane32_swap per dword pairs quad 2m with quad 2m+1 so that the lower half
+        // stores channels 16m..16m+7 and the upper half 16m+8..16m+15: 16-byte stores, half as many.
 #pragma unroll
-            for (int j = 0; j < 4; ++j) h[j] = (half_t)v[j];
-            *reinterpret_cast<half4*>(p.y16 + pix * p.Cout + co) = h;
-          }
-          if (p.y32) *reinterpret_cast<f32x4*>(p.y32 + pix * p.Cout + co) = v;
+        for (int m = 0; m < 2; ++m) {
+          auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * m][0], pk[2 * m + 1][0], false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * m][1], pk[2 * m + 1][1], false, false);
+          u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+          const int co = n0 + (wn * NT + nt) * 32 + 16 * m + 8 * kgrp;
+          if (inside) *reinterpret_cast<u32x4*>(p.y16 + pix * p.Cout + co) = o;
         }
       }
     }
