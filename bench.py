@@ -62,7 +62,7 @@ def pmc_traffic(batch, size):
     """HBM bytes per conv3x3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
     separate runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read
     from inside this process, so the figure is the profile of this exact workload; null otherwise."""
-    path = os.path.join(ROOT, 'profiles', 'r01_v4_pmc_conv3x3.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_final_pmc_conv3x3.json')
     if batch != PMC_BATCH or size != 512 or not os.path.exists(path):
         return None
     return json.load(open(path))['hbm_bytes_per_launch_corrected']
@@ -183,7 +183,7 @@ def main():
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / MFMA_F16_DENSE_PEAK_TFLOPS, 'traffic': pmc_traffic(B, S),
-                'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_v4_pmc_hbm.csv)',
+                'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_final_pmc_hbm.csv)',
                 'algorithmic_bytes_per_launch': conv['bytes'] / max(1, conv['launches']),
                 'kernel': 'conv3x3_mfma_kernel (all launches of the class)',
                 'launches': conv['launches'], 'avg_launch_ms': conv['ms'] / max(1, conv['launches']),

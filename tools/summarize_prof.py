@@ -4,7 +4,7 @@ import json, os, sqlite3, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 batch = sys.argv[3] if len(sys.argv) > 3 else '16'
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
 os.makedirs(out, exist_ok=True)
 
 def q(db, sql):
