@@ -339,23 +339,23 @@ __device__ __forceinline__ void sweep_pair(int j, int s, int& p, int& q) {
 // are mirrored in two small compact arrays (DO: diagonal D[2][N] and pair elements O[2][N/2]), kept
 // current by the threads that own them; reading them straight out of the float2 image costs three
 // 4-way bank-conflicted loads per thread and set (the diagonal has stride 2(N+2) dwords).
-template <int MODE, int N>
+// KB = 2x2 blocks per thread (rows k, k + NP/KB, ...; one column pair l): rotation(l) is derived once
+// per thread and reused for its KB blocks.
+template <int MODE, int N, int KB>
 __device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& my_off) {
-  constexpr int NP = N / 2, PITCH = N + 1, IMG = N * PITCH;
+  constexpr int NP = N / 2, PITCH = N + 1, IMG = N * PITCH, KS = NP / KB;
   constexpr int NSETS = MODE == SWEEP_CROSS ? NP : NP - 1;
-  const int k = t / NP, l = t % NP;
-  const int src_lane = (t & (64 - NP)) | k;      // lane of my wave whose l equals my k
+  const int kq = t / NP, l = t % NP;
   float* const Dg = DO;                          // [2][N]
   float* const Og = DO + 2 * N;                  // [2][NP]
   if (MODE == SWEEP_CROSS) {
-    if (t < N) Dg[t] = SQ[t * PITCH + t][0];
-    if (t < NP) Og[t] = SQ[t * PITCH + NP + t][0];      // set 0 pairs j with NP + j
+    for (int i = t; i < N; i += NP * KS) Dg[i] = SQ[i * PITCH + i][0];
+    for (int i = t; i < NP; i += NP * KS) Og[i] = SQ[i * PITCH + NP + i][0];      // set 0 pairs j with NP + j
     __syncthreads();
   }
   int cur = 0;
   for (int s = 0; s < NSETS; ++s) {
-    int pk, qk, pl, ql;
-    sweep_pair<MODE, N>(k, s, pk, qk);
+    int pl, ql;
     sweep_pair<MODE, N>(l, s, pl, ql);
     const f32x2* C0 = SQ + cur * IMG;
     f32x2* N0 = SQ + (cur ^ 1) * IMG;
@@ -363,26 +363,37 @@ __device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& m
     float lpp, lqq, lpq;
     if (MODE == SWEEP_CROSS) { lpp = Dg[cur * N + pl]; lqq = Dg[cur * N + ql]; lpq = Og[cur * NP + l]; }
     else { lpp = C0[pl * PITCH + pl][0]; lqq = C0[ql * PITCH + ql][0]; lpq = C0[pl * PITCH + ql][0]; }
-    const f32x2 app = C0[pk * PITCH + pl], apq = C0[pk * PITCH + ql];
-    const f32x2 aqp = C0[qk * PITCH + pl], aqq = C0[qk * PITCH + ql];
+    int pk[KB], qk[KB];
+    f32x2 app[KB], apq[KB], aqp[KB], aqq[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      sweep_pair<MODE, N>(kq + i * KS, s, pk[i], qk[i]);
+      app[i] = C0[pk[i] * PITCH + pl]; apq[i] = C0[pk[i] * PITCH + ql];
+      aqp[i] = C0[qk[i] * PITCH + pl]; aqq[i] = C0[qk[i] * PITCH + ql];
+    }
     float cl, sl, offl;
     jacobi_rotation(lpp, lqq, lpq, cl, sl, offl);
-    const float ck = __shfl(cl, src_lane, 64), sk = __shfl(sl, src_lane, 64);
     my_off = fmaxf(my_off, offl);
-    // S: columns (pair l), then rows (pair k);  Q: columns only
-    const float ypp = cl * app[0] - sl * apq[0], ypq = sl * app[0] + cl * apq[0];
-    const float yqp = cl * aqp[0] - sl * aqq[0], yqq = sl * aqp[0] + cl * aqq[0];
-    f32x2 npp, npq, nqp, nqq;
-    npp[0] = ck * ypp - sk * yqp;  npq[0] = ck * ypq - sk * yqq;
-    nqp[0] = sk * ypp + ck * yqp;  nqq[0] = sk * ypq + ck * yqq;
-    npp[1] = cl * app[1] - sl * apq[1];  npq[1] = sl * app[1] + cl * apq[1];
-    nqp[1] = cl * aqp[1] - sl * aqq[1];  nqq[1] = sl * aqp[1] + cl * aqq[1];
-    N0[pk * PITCH + pl] = npp;  N0[pk * PITCH + ql] = npq;
-    N0[qk * PITCH + pl] = nqp;  N0[qk * PITCH + ql] = nqq;
-    if (MODE == SWEEP_CROSS) {
-      const int nx = cur ^ 1;
-      if (k == l) { Dg[nx * N + pk] = npp[0]; Dg[nx * N + qk] = nqq[0]; }
-      if (l == ((k + 1) & (NP - 1))) Og[nx * NP + k] = npq[0];     // S[p_k][q_k] of the next set
+    const int nx = cur ^ 1;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int k = kq + i * KS;
+      const int src_lane = (t & (64 - NP)) | k;      // lane of my wave whose l equals this k
+      const float ck = __shfl(cl, src_lane, 64), sk = __shfl(sl, src_lane, 64);
+      // S: columns (pair l), then rows (pair k);  Q: columns only
+      const float ypp = cl * app[i][0] - sl * apq[i][0], ypq = sl * app[i][0] + cl * apq[i][0];
+      const float yqp = cl * aqp[i][0] - sl * aqq[i][0], yqq = sl * aqp[i][0] + cl * aqq[i][0];
+      f32x2 npp, npq, nqp, nqq;
+      npp[0] = ck * ypp - sk * yqp;  npq[0] = ck * ypq - sk * yqq;
+      nqp[0] = sk * ypp + ck * yqp;  nqq[0] = sk * ypq + ck * yqq;
+      npp[1] = cl * app[i][1] - sl * apq[i][1];  npq[1] = sl * app[i][1] + cl * apq[i][1];
+      nqp[1] = cl * aqp[i][1] - sl * aqq[i][1];  nqq[1] = sl * aqp[i][1] + cl * aqq[i][1];
+      N0[pk[i] * PITCH + pl] = npp;  N0[pk[i] * PITCH + ql] = npq;
+      N0[qk[i] * PITCH + pl] = nqp;  N0[qk[i] * PITCH + ql] = nqq;
+      if (MODE == SWEEP_CROSS) {
+        if (k == l) { Dg[nx * N + pk[i]] = npp[0]; Dg[nx * N + qk[i]] = nqq[0]; }
+        if (l == ((k + 1) & (NP - 1))) Og[nx * NP + k] = npq[0];     // S[p_k][q_k] of the next set
+      }
     }
     cur ^= 1;
     __syncthreads();
@@ -390,10 +401,14 @@ __device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& m
   return cur;
 }
 
+// measured (tools/probe/jacobi_probe.hip): more blocks per thread is SLOWER (N = 64: 1761 / 1930 / 2412 / 3643 cycles per
+// set for KB = 1 / 2 / 4 / 8; with two blocks resident per CU 2910 vs 3010) -- fewer waves hide less LDS latency -- so KB = 1
+template <int M2> struct JacobiCfg { static constexpr int KB = 1; static constexpr int NT = (M2 / 2) * (M2 / 2) / KB; };
+
 // One outer step: pair problem of blocks (bi, bj) -> rotation matrix Q (M2 x M2) in Qbuf.
 template <int M2>
-__global__ __launch_bounds__((M2 / 2) * (M2 / 2)) void jacobi_diag_kernel(float* A, float* Qbuf, JacobiState* st, int C, int step) {
-  constexpr int B = M2 / 2, PITCH = M2 + 1, NT = B * B;
+__global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A, float* Qbuf, JacobiState* st, int C, int step) {
+  constexpr int B = M2 / 2, PITCH = M2 + 1, NT = JacobiCfg<M2>::NT, KB = JacobiCfg<M2>::KB;
   const int m = blockIdx.y, g = blockIdx.x;
   if (st[m].done) return;
   extern __shared__ __attribute__((aligned(16))) float jsm[];
@@ -413,7 +428,7 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2)) void jacobi_diag_kernel(float*
   float my_off = 0.f;
   __syncthreads();
   float* DO = jsm + 4 * M2 * PITCH;                   // after the two float2 images
-  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2>(SQ, DO, tid, my_off) : jacobi_sets<SWEEP_CROSS, M2>(SQ, DO, tid, my_off);
+  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, my_off) : jacobi_sets<SWEEP_CROSS, M2, KB>(SQ, DO, tid, my_off);
   float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
   for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
   for (int o = 32; o > 0; o >>= 1) my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
@@ -595,7 +610,7 @@ static void jacobi_enqueue_sweep(const JacobiGroup* grp, int ngrp, int C) {
   for (int step = -1; step < nblk - 1; ++step)
     for (int g = 0; g < ngrp; ++g) {
       const JacobiGroup& G = grp[g];
-      hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3((M2 / 2) * (M2 / 2)), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
+      hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3(JacobiCfg<M2>::NT), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
       hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3((M2 == 64 ? npair * (npair + 1) / 2 : npair * npair) + npair * npair, G.nmat),
                          dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
     }
