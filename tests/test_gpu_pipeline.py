@@ -254,3 +254,56 @@ def test_swap5_pipeline(ctx, weights):
     t2 = ops.adain(ctx.encode(x, 'relu2_1'), ctx.encode(s01, 'relu2_1'), 0.8, ctx=ctx)[0]
     x = ctx.decode(t2, 'relu2_1')
     assert np.array_equal(got, np.uint8(np.clip(x, 0, 1) * 255))
+
+
+def test_config5_1024_content_512_style_adain_keepcolors(ctx, weights):
+    """BASELINE config 5: 1024x1024 content / 512x512 style, --keep-colors CORAL first, then the --adain
+    branch AND the WCT branch.  Full size, so properties instead of an oracle run: CORAL against the
+    float64 oracle within 1 LSB; determinism; AdaIN at alpha = 1 gives every level's output the style's
+    per-channel mean/std; the WCT branch reproduces the style covariance on the 1024^2-derived features."""
+    from wct_tf_amd import ops, _lib
+    content = synthetic_image(1005, 1024, 1024)
+    style = synthetic_image(2005, 512, 512)
+    style_cc = ops.preserve_colors_np(style, content, ctx=ctx)
+    want_cc = oracle.preserve_colors_np(style, content)
+    d = np.abs(style_cc.astype(int) - want_cc.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3
+    out_a = ctx.stylize(content, style_cc, RELU_TARGETS, alpha=0.8, adain=True)
+    out_b = ctx.stylize(content, style_cc, RELU_TARGETS, alpha=0.8, adain=True)
+    assert out_a.shape == (1024, 1024, 3) and np.array_equal(out_a, out_b)
+    out_w = ctx.stylize(content, style_cc, RELU_TARGETS, alpha=0.8)
+    assert out_w.shape == (1024, 1024, 3) and not np.array_equal(out_w, out_a)
+    c01, s01 = np.float32(content / 255.), np.float32(style_cc / 255.)
+    for relu in ('relu4_1', 'relu1_1'):
+        fc, fs = ctx.encode(c01, relu), ctx.encode(s01, relu)
+        ch = fc.shape[-1]
+        y = ops.adain(fc, fs, 1.0, ctx=ctx)[0].reshape(-1, ch).astype(np.float64)
+        s2 = fs.reshape(-1, ch).astype(np.float64)
+        assert np.abs(y.mean(0) - s2.mean(0)).max() < 1e-3 * max(1.0, np.abs(s2.mean(0)).max())
+        assert np.abs(y.std(0) - s2.std(0)).max() < 2e-3 * max(1.0, s2.std(0).max())
+    fc, fs = ctx.encode(c01, 'relu3_1'), ctx.encode(s01, 'relu3_1')       # Nc = 65536, Ns = 16384
+    out = ctx.transform(fc.reshape(-1, 256), fs.reshape(-1, 256), 1.0, _lib.WCT_TF).astype(np.float64)
+    s2 = fs.reshape(-1, 256).astype(np.float64)
+    assert np.linalg.norm(np.cov(out.T) - np.cov(s2.T)) / np.linalg.norm(np.cov(s2.T)) < 5e-3
+
+
+def test_abi_error_paths_on_gpu(ctx):
+    """Errors cross the ABI as status codes with a message (no exceptions, no silent fallback)."""
+    import ctypes as C
+    from wct_tf_amd import _lib
+    from wct_tf_amd.context import Context
+    from wct_tf_amd._lib import WCTHipError
+    fresh = Context(0)
+    try:
+        with pytest.raises(WCTHipError, match='encoder weights not set'):
+            fresh.encode(np.zeros((16, 16, 3), np.float32), 'relu1_1')
+        with pytest.raises(WCTHipError, match='decoder weights'):
+            fresh.decode(np.zeros((4, 4, 64), np.float32), 'relu1_1')
+        with pytest.raises(WCTHipError, match='invalid argument'):
+            fresh.transform(np.zeros((8, 48), np.float32), np.zeros((8, 48), np.float32), 0.5, _lib.WCT_NP)   # C % 32
+        with pytest.raises(ValueError):
+            fresh.set_decoder('relu2_1', [(np.zeros((3, 3, 128, 64), np.float32), np.zeros(64, np.float32))])   # 3 layers needed
+    finally:
+        fresh.close()
+    with pytest.raises(WCTHipError):
+        Context(99)                                           # no such device
