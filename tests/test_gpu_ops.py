@@ -173,6 +173,8 @@ def _h(x):
     (128, 128, 64, 64, True, False),     # 16x16 tile, BN=64
     (96, 96, 128, 128, True, False),     # 16x16 tile, BN=128
     (4, 4, 64, 64, True, True),
+    (360, 376, 64, 64, True, False),     # tall 32x16 tile config, ragged edge
+    (184, 180, 64, 64, False, True),     # same with the upsample folded in, no ReLU
 ])
 def test_conv3x3(ctx, h, w, cin, cout, relu, up):
     rng = np.random.default_rng(h * 1000 + cin)
