@@ -32,7 +32,7 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
 
-@pytest.mark.parametrize('size', [(64, 64), (72, 56)])
+@pytest.mark.parametrize('size', [(64, 64), (72, 56), (50, 38)])
 def test_encoder_all_levels(ctx, weights, size):
     img = np.float32(synthetic_image(7, *size) / 255.)
     want = oracle.encode(img, weights, RELU_TARGETS)

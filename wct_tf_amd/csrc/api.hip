@@ -363,14 +363,15 @@ static void level_dims(int H, int W, int level, int* h, int* w) {
 }
 
 static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16, float* y32,
-                    int B, int H, int W, int upsample, int relu) {
+                    int B, int H, int W, int upsample, int relu, int pool = 0) {
   ConvArgs a;
   a.x = x; a.w = l.w; a.bias = l.b; a.y16 = y16; a.y32 = y32;
-  a.B = B; a.H = H; a.W = W; a.Cin = l.cin; a.Cout = l.cout; a.upsample = upsample; a.relu = relu;
+  a.B = B; a.H = H; a.W = W; a.Cin = l.cin; a.Cout = l.cout; a.upsample = upsample; a.relu = relu; a.pool = pool;
   const double px = (double)B * H * W;
   const double in_px = upsample ? px / 4 : px;
+  const double out_px = pool ? (double)B * ((H + 1) / 2) * ((W + 1) / 2) : px;
   ProfScope ps(c, 0, 2.0 * px * 9 * l.cin * l.cout,
-               in_px * l.cin * 2 + px * l.cout * ((y16 ? 2 : 0) + (y32 ? 4 : 0)) + 9.0 * l.cin * l.cout * 2);
+               in_px * l.cin * 2 + out_px * l.cout * ((y16 ? 2 : 0) + (y32 ? 4 : 0)) + 9.0 * l.cin * l.cout * 2);
   return launch_conv3x3(a, c->stream);
 }
 
@@ -394,23 +395,29 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
     TRY(launch_conv_first(a, c->stream));
   }
   if (deepest == 1) return WCT_OK;
-  // (layer index into enc[], level whose relu*_1 it produces or 0, pool before it?)
+  // enc[i]: level whose relu*_1 it produces (0 = none), and whether a 'same' max-pool follows it
+  // (conv1_2, conv2_2, conv3_4, conv4_4 -- their outputs feed nothing but the pool, so it is fused
+  // into their epilogue; WCT_FUSE_POOL=0 runs the separate pool kernel instead)
   static const int seq_tap[12] = {0, 2, 0, 3, 0, 0, 0, 4, 0, 0, 0, 5};
-  static const int pool_before[12] = {0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+  static const int pool_after[12] = {1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0};
+  static const int fuse_pool = getenv("WCT_FUSE_POOL") ? atoi(getenv("WCT_FUSE_POOL")) : 1;
   int h = H, w = W;
   for (int i = 0; i < 12; ++i) {
     const ConvLayer& l = c->enc[i];
-    if (pool_before[i]) {
-      ProfScope ps(c, 3, 0, (double)B * h * w * l.cin * 2 * 1.25);
-      TRY(launch_maxpool2x2(cur, nxt, B, h, w, l.cin, c->stream));
-      h = (h + 1) / 2; w = (w + 1) / 2;
-      half_t* t = cur; cur = nxt; nxt = t;
-    }
     const int tap = seq_tap[i];
     const bool last = tap == deepest;
-    TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1));
+    const bool fuse = pool_after[i] && fuse_pool;
+    TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1, fuse));
     half_t* t = cur; cur = nxt; nxt = t;
     if (last) break;
+    if (pool_after[i]) {
+      if (!fuse) {
+        ProfScope ps(c, 3, 0, (double)B * h * w * l.cout * 2 * 1.25);
+        TRY(launch_maxpool2x2(cur, nxt, B, h, w, l.cout, c->stream));
+        t = cur; cur = nxt; nxt = t;
+      }
+      h = (h + 1) / 2; w = (w + 1) / 2;
+    }
   }
   return WCT_OK;
 }

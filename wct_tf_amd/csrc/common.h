@@ -49,6 +49,7 @@ struct ConvArgs {
   int Cin, Cout;
   int upsample;        // input is the x2 nearest upsample of x (model.py:293)
   int relu;
+  int pool;            // fuse the following 2x2/2 'same' max-pool: outputs are [(H+1)/2][(W+1)/2][Cout]
 };
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 

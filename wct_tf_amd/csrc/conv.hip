@@ -212,15 +212,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
     __syncthreads();
   }
 
-  // --- epilogue: bias, ReLU, store.  acc register r of a 32x32 tile holds
-  // channel (r&3) + 8*(r>>2) + 4*(lane>>5) of pixel lane&31.
-  const size_t out_base = (size_t)b * p.H * p.W;
+  // --- epilogue: bias, ReLU, (2x2 max-pool), store.  acc register r of a 32x32 tile holds
+  // channel (r&3) + 8*(r>>2) + 4*(lane>>5) of pixel lane&31 (= tile row (lane&31)>>4, column lane&15).
+  // With p.pool the 2x2/2 'same' max-pool that follows conv1_2 / conv2_2 / conv3_4 / conv4_4
+  // (vgg_normalised.py:42) is taken here: an MFMA pixel tile is 2 rows x 16 columns starting at even
+  // coordinates, so every pooling window lies inside one tile: max with lane^1 (column pair) and
+  // lane^16 (row pair); cells outside the image are 0, neutral after the ReLU (ceil-mode edge).
+  const int Ho = p.pool ? (p.H + 1) / 2 : p.H, Wo = p.pool ? (p.W + 1) / 2 : p.W;
+  const size_t out_base = (size_t)b * Ho * Wo;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int oy = y0 + (wm * MT + mt) * 2 + frag_py;
     const int ox = x0 + frag_px;
-    const bool inside = oy < p.H && ox < p.W;
-    const size_t pix = out_base + (size_t)oy * p.W + ox;
+    const bool in_img = oy < p.H && ox < p.W;
+    const bool inside = p.pool ? (in_img && frag_py == 0 && (frag_px & 1) == 0) : in_img;
+    const size_t pix = out_base + (p.pool ? (size_t)(oy >> 1) * Wo + (ox >> 1) : (size_t)oy * p.W + ox);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       unsigned pk[4][2];                      // fp16 x4 of each register quad, packed
@@ -234,9 +240,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
           float t = acc[nt][mt][rq * 4 + j] + bv[j];
           v[j] = p.relu ? fmaxf(t, 0.f) : t;
         }
-        if (inside && p.y32) *reinterpret_cast<f32x4*>(p.y32 + pix * p.Cout + co) = v;
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2 lo = {(half_t)v[0], (half_t)v[1]}, hi = {(half_t)v[2], (half_t)v[3]};
+        if (p.pool) {
+          // on the packed fp16 pairs (rounding is monotonic, so max-after-round == round-after-max):
+          // column pair by DPP quad_perm(1,0,3,2), row pair by ds_swizzle xor 16
+          const h2 zero = {(half_t)0.f, (half_t)0.f};
+          h2 q[2] = {in_img ? lo : zero, in_img ? hi : zero};
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            int t = __builtin_bit_cast(int, q[d]);
+            h2 o = __builtin_bit_cast(h2, __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true));
+            q[d] = __builtin_elementwise_max(q[d], o);
+            t = __builtin_bit_cast(int, q[d]);
+            o = __builtin_bit_cast(h2, __builtin_amdgcn_ds_swizzle(t, 0x401F));
+            q[d] = __builtin_elementwise_max(q[d], o);
+          }
+          lo = q[0]; hi = q[1];
+        } else if (inside && p.y32) {
+          *reinterpret_cast<f32x4*>(p.y32 + pix * p.Cout + co) = v;
+        }
         pk[rq][0] = __builtin_bit_cast(unsigned, lo);
         pk[rq][1] = __builtin_bit_cast(unsigned, hi);
       }
@@ -272,6 +295,7 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
 int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK(a.Cin % BK == 0 && a.Cout % 64 == 0 && a.H > 1 && a.W > 1 && a.B > 0);
   ARG_CHECK(!a.upsample || (a.H % 2 == 0 && a.W % 2 == 0));
+  ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
   const long px16 = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.B;
   const long px32 = (long)cdiv(a.W, TW) * cdiv(a.H, 32) * a.B;
