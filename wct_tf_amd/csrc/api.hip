@@ -258,14 +258,20 @@ static int upload(wct_ctx* c, const void* host, size_t bytes, void** dev) {
   return WCT_OK;
 }
 
-// HWIO fp32 -> [cout][tap][cin] fp16
+// HWIO fp32 -> fp16 MFMA A-fragments [cout/32][tap][cin/16][lane][8]: lane l of a fragment holds output
+// channel 32*T + (l & 31), input channels 16*k16 + 8*(l >> 5) .. +7 (the v_mfma_f32_32x32x16_f16 A layout),
+// so a wave fetches a fragment with ONE fully coalesced 1-KiB load
 static int pack_conv(wct_ctx* c, const float* w_hwio, const float* b, int cin, int cout, ConvLayer* out) {
   free_layer(*out);
   std::vector<half_t> packed((size_t)cout * 9 * cin);
+  const int c16 = cin / 16;
   for (int tap = 0; tap < 9; ++tap)
     for (int ci = 0; ci < cin; ++ci)
-      for (int co = 0; co < cout; ++co)
-        packed[((size_t)co * 9 + tap) * cin + ci] = (half_t)w_hwio[((size_t)tap * cin + ci) * cout + co];
+      for (int co = 0; co < cout; ++co) {
+        const int lane = (co & 31) + 32 * ((ci >> 3) & 1);
+        const size_t frag = ((size_t)(co >> 5) * 9 + tap) * c16 + (ci >> 4);
+        packed[(frag * 64 + lane) * 8 + (ci & 7)] = (half_t)w_hwio[((size_t)tap * cin + ci) * cout + co];
+      }
   TRY(upload(c, packed.data(), packed.size() * sizeof(half_t), (void**)&out->w));
   TRY(upload(c, b, (size_t)cout * sizeof(float), (void**)&out->b));
   out->cin = cin; out->cout = cout;
