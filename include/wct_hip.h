@@ -86,7 +86,8 @@ int wct_set_style_swap(wct_ctx* ctx, float ss_alpha, int patch_size, int stride)
 int wct_eigh(wct_ctx* ctx, const float* A, int C, int nmat, float* evals, float* evecs,
              int* sweeps_out /* [nmat] or NULL */);
 /* Conv2DReflect (ops.py:17-19): x [H][W][Cin] fp32, w HWIO, y [Ho][Wo][Cout] fp32;
- * upsample!=0 applies UpSampling2D x2 first (model.py:293). fp16 operands, fp32 accumulate. */
+ * upsample!=0 applies UpSampling2D x2 first (model.py:293). fp16 operands, fp32 accumulate.
+ * Cin and Cout must be multiples of 64 (every 3x3 layer of the path but conv1_1 / the output conv). */
 int wct_conv3x3(wct_ctx* ctx, const float* x, int H, int W, int Cin, const float* w_hwio,
                 const float* bias, int Cout, int relu, int upsample, float* y);
 /* MaxPooling2D(padding='same') (vgg_normalised.py:42): y [(H+1)/2][(W+1)/2][C] */

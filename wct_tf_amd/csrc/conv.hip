@@ -106,202 +106,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[N
   }
 }
 
+// ---------------------------------------------------------------------------
+// Implicit GEMM per 256-thread block: a TH x 16 pixel tile x BN output channels, K = 9 taps x Cin in
+// chunks of 32 input channels.
+//  * pixels (MFMA B operand): the (TH+2) x 18 halo patch of a K-chunk is staged through LDS in 16-B
+//    pieces with an XOR swizzle (conflict-free ds_read_b128); a wave reads one k-step of fragments
+//    (8 MFMAs) ahead, with immediate offsets only (taps are compile-time in the 18-tap unrolled body);
+//  * weights (A operand): pre-packed as MFMA fragments, every wave streams its own fragments straight
+//    from global memory (L2-resident: all blocks read the same weights) into VGPRs with one fully
+//    coalesced 1-KiB buffer_load_dwordx4 per fragment, a full tap (16 MFMAs) ahead.  No weight traffic
+//    through LDS, no ds_write pass, no per-tap barrier: the waves of a block only meet when the patch
+//    changes, every 9 taps.  (The first version staged weights through LDS with a barrier per tap:
+//    771 TFLOP/s over the layer mix vs 943 for this one.)
+//  * __launch_bounds__(256, 2): two blocks resident per CU cover each other's chunk boundaries.
+// ---------------------------------------------------------------------------
 template <int TH, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
-  constexpr int PH = TH + 2;
-  constexpr int MT = (TH / 2) / WM;          // 32-pixel MFMA tiles per wave
-  constexpr int NT = (BN / 32) / WN;         // 32-channel MFMA tiles per wave
-  constexpr int PATCH_ITEMS = PH * 18 * 4;   // 16-byte pieces per K-chunk
-  constexpr int PATCH_PER_THREAD = (PATCH_ITEMS + 255) / 256;
-  constexpr int W_ITEMS = BN * 4;
-  constexpr int W_PER_THREAD = (W_ITEMS + 255) / 256;
-  constexpr int PATCH_BYTES = PH * PITCH * 64;
-  constexpr int W_BYTES = BN * 64;
-  constexpr int DUMP_OFF = PATCH_BYTES + 2 * W_BYTES;   // 4 KiB dump area (relative to smem)
-  // Register-prefetching the next K-chunk's halo patch costs PATCH_PER_THREAD x 4 VGPRs for the whole
-  // loop; the tall tile spends them on accumulators instead and reloads the patch at the (rare) chunk
-  // boundary, where the second resident block of the CU covers the bubble.
-  constexpr bool PREFETCH_PATCH = TH <= 16;
-
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS map: ONE patch buffer at 0 (it changes every 9th iteration only), two weight buffers, dump
-  unsigned char* const patch_lds = smem;
-  auto w_buf = [&](int i) -> unsigned char* { return smem + PATCH_BYTES + i * W_BYTES; };
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-
-  int bid = blockIdx.x;
-  const int ntile = bid % n_tiles;
-  bid /= n_tiles;
-  const int tx = bid % tiles_x;
-  const int ty = bid / tiles_x;
-  const int b = blockIdx.y;
-  const int y0 = ty * TH, x0 = tx * TW;
-  const int n0 = ntile * BN;
-
-  const int Hin = p.upsample ? p.H / 2 : p.H;
-  const int Win = p.upsample ? p.W / 2 : p.W;
-  const half_t* xb = p.x + (size_t)b * Hin * Win * p.Cin;
-
-  // --- per-thread source offsets of the patch pieces (element offsets, without the chunk base)
-  int patch_src[PATCH_PER_THREAD];
-  int patch_dst[PATCH_PER_THREAD];
-#pragma unroll
-  for (int i = 0; i < PATCH_PER_THREAD; ++i) {
-    int item = tid + i * 256;
-    int valid = item < PATCH_ITEMS;
-    int pix = valid ? item >> 2 : 0;
-    int chunk = item & 3;
-    int py = pix / 18, px = pix - py * 18;
-    int iy = reflect_idx(y0 - 1 + py, p.H);
-    int ix = reflect_idx(x0 - 1 + px, p.W);
-    if (p.upsample) { iy >>= 1; ix >>= 1; }
-    // tail lanes past the last piece re-read piece 0 and park it in a dump slot: no branches in the loop
-    patch_src[i] = valid ? (iy * Win + ix) * p.Cin + chunk * 8 : 0;
-    patch_dst[i] = valid ? ((py * PITCH + px) * 4 + (chunk ^ ((px >> 2) & 3))) * 16 : DUMP_OFF + tid * 16;
-  }
-  int w_src[W_PER_THREAD];
-  int w_dst[W_PER_THREAD];
-#pragma unroll
-  for (int i = 0; i < W_PER_THREAD; ++i) {
-    int item = tid + i * 256;
-    int valid = item < W_ITEMS;
-    int n = valid ? item >> 2 : 0;
-    int chunk = item & 3;
-    // weights are fragment-packed [cout/32][tap][cin/16][lane][8]: piece (n, chunk) of a K-chunk is lane
-    // (n&31) + 32*(chunk&1) of fragment cin16 = 2*kchunk + (chunk>>1)
-    w_src[i] = valid ? (((n0 + n) >> 5) * 9 * (p.Cin >> 4) + (chunk >> 1)) * 512 + ((n & 31) + 32 * (chunk & 1)) * 8 : 0;
-    w_dst[i] = valid ? PATCH_BYTES + (n * 4 + (chunk ^ ((n >> 2) & 3))) * 16 : DUMP_OFF + tid * 16;
-  }
-
-  // --- fragment read offsets
-  // B (pixels): lane -> pixel (row (l&31)>>4, col l&15), k-group l>>5
-  const int frag_px = lane & 15;
-  const int frag_py = (lane & 31) >> 4;
-  const int kgrp = lane >> 5;
-  // A (weights): lane -> channel l&31, k-group l>>5
-  int a_off[NT][2];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    int n = (wn * NT + nt) * 32 + (lane & 31);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      int chunk = ks * 2 + kgrp;
-      a_off[nt][ks] = (n * 4 + (chunk ^ ((n >> 2) & 3))) * 16;
-    }
-  }
-
-  f32x16 acc[NT][MT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
-
-  const int n_chunks = p.Cin / BK;
-  const int n_iter = n_chunks * 9;
-
-  u32x4 patch_regs[PATCH_PER_THREAD];
-  u32x4 w_regs[W_PER_THREAD];
-
-  // prologue: chunk 0 patch + tap 0 weights
-#pragma unroll
-  for (int i = 0; i < PATCH_PER_THREAD; ++i)
-    patch_regs[i] = *reinterpret_cast<const u32x4*>(xb + patch_src[i]);
-#pragma unroll
-  for (int i = 0; i < W_PER_THREAD; ++i)
-    w_regs[i] = *reinterpret_cast<const u32x4*>(p.w + w_src[i]);
-#pragma unroll
-  for (int i = 0; i < PATCH_PER_THREAD; ++i)
-    *reinterpret_cast<u32x4*>(smem + patch_dst[i]) = patch_regs[i];
-#pragma unroll
-  for (int i = 0; i < W_PER_THREAD; ++i)
-    *reinterpret_cast<u32x4*>(smem + w_dst[i]) = w_regs[i];
-  __syncthreads();
-
-  for (int it = 0; it < n_iter; ++it) {
-    const int chunk_i = it / 9;
-    const int tap = it - chunk_i * 9;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const int wbuf = it & 1;
-    const bool has_next = it + 1 < n_iter;
-    const bool next_patch = has_next && tap == 8;
-
-    // 1) issue the global loads of the next stage
-    if (has_next) {
-      const int ntap = tap == 8 ? 0 : tap + 1;
-      const int nchunk = tap == 8 ? chunk_i + 1 : chunk_i;
-      const int wbase = (ntap * (p.Cin >> 4) + nchunk * 2) * 512;
-#pragma unroll
-      for (int i = 0; i < W_PER_THREAD; ++i)
-        w_regs[i] = *reinterpret_cast<const u32x4*>(p.w + w_src[i] + wbase);
-      if (PREFETCH_PATCH && next_patch) {
-        const int cbase = nchunk * BK;
-#pragma unroll
-        for (int i = 0; i < PATCH_PER_THREAD; ++i)
-          patch_regs[i] = *reinterpret_cast<const u32x4*>(xb + patch_src[i] + cbase);
-      }
-    }
-
-    // 2) MFMAs on the current stage
-    const unsigned char* wl = w_buf(wbuf);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 afrag[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) afrag[nt] = *reinterpret_cast<const half8*>(wl + a_off[nt][ks]);
-      const int chunk = ks * 2 + kgrp;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int py = (wm * MT + mt) * 2 + frag_py + ky;
-        const int px = frag_px + kx;
-        const int off = ((py * PITCH + px) * 4 + (chunk ^ ((px >> 2) & 3))) * 16;
-        half8 bfrag = *reinterpret_cast<const half8*>(patch_lds + off);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afrag[nt], bfrag, acc[nt][mt], 0, 0, 0);
-      }
-    }
-
-    // 3) park the prefetched weights in the other buffer; at a chunk boundary replace the patch
-    //    once every wave has finished reading it
-    if (has_next) {
-#pragma unroll
-      for (int i = 0; i < W_PER_THREAD; ++i)
-        *reinterpret_cast<u32x4*>(smem + (wbuf ^ 1) * W_BYTES * (w_dst[i] < DUMP_OFF) + w_dst[i]) = w_regs[i];
-      if (next_patch) {
-        __syncthreads();
-        if (!PREFETCH_PATCH) {
-          const int cbase = (chunk_i + 1) * BK;
-#pragma unroll
-          for (int i = 0; i < PATCH_PER_THREAD; ++i)
-            patch_regs[i] = *reinterpret_cast<const u32x4*>(xb + patch_src[i] + cbase);
-        }
-#pragma unroll
-        for (int i = 0; i < PATCH_PER_THREAD; ++i)
-          *reinterpret_cast<u32x4*>(smem + patch_dst[i]) = patch_regs[i];
-      }
-    }
-    __syncthreads();
-  }
-
-  conv_epilogue<MT, NT>(p, acc, b, y0, x0, n0, wm, wn, lane);
-}
-
-// ---------------------------------------------------------------------------
-// Weight-streaming variant: the pixel patch is staged through LDS as above, but every wave
-// loads its weight fragments straight from the fragment-packed global array into VGPRs (one
-// fully coalesced 1-KiB global_load_dwordx4 per fragment, L2-resident: every block reads the same
-// weights), one tap ahead of the MFMAs.  No weight traffic through LDS (the LDS pipe carried
-// 12 KiB per wave per tap, 75 % of the MFMA time with two blocks per CU; now 8 KiB), no
-// ds_write pass and no per-tap barrier: the waves only meet when the patch changes, every 9 taps.
-// ---------------------------------------------------------------------------
-template <int TH, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv3x3_wstream_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
   constexpr int PH = TH + 2;
   constexpr int MT = (TH / 2) / WM;
   constexpr int NT = (BN / 32) / WN;
@@ -470,18 +290,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wstream_kernel(ConvArgs p, int
 }
 
 template <int TH, int BN, int WM, int WN>
-static int launch_conv_cfg(const ConvArgs& a, hipStream_t s, bool wstream) {
+static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
   const int n_tiles = a.Cout / BN;
   constexpr int PH = TH + 2;
+  const size_t lds = (size_t)PH * PITCH * 64 + 4096;
   dim3 grid(tiles_x * tiles_y * n_tiles, a.B);
-  if (wstream) {
-    const size_t lds = (size_t)PH * PITCH * 64 + 4096;
-    hipLaunchKernelGGL((conv3x3_wstream_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
-  } else {
-    const size_t lds = (size_t)PH * PITCH * 64 + 2 * (size_t)BN * 64 + 4096;
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
-  }
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
@@ -490,16 +305,14 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK(a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.H > 1 && a.W > 1 && a.B > 0);
   ARG_CHECK(!a.upsample || (a.H % 2 == 0 && a.W % 2 == 0));
   ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
-  // bit i of WCT_CONV_WSTREAM selects the weight-streaming kernel for config i (experiment switch)
-  static const int ws = getenv("WCT_CONV_WSTREAM") ? atoi(getenv("WCT_CONV_WSTREAM")) : 0;
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
   const long px16 = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.B;
   const long px32 = (long)cdiv(a.W, TW) * cdiv(a.H, 32) * a.B;
-  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) return launch_conv_cfg<16, 128, 2, 2>(a, s, ws & 1);
-  if (px32 * (a.Cout / 64) >= 512) return launch_conv_cfg<32, 64, 4, 1>(a, s, ws & 2);      // 512 px x 64 ch
-  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_conv_cfg<16, 128, 2, 2>(a, s, ws & 1);
-  if (px16 * (a.Cout / 64) >= 256) return launch_conv_cfg<16, 64, 4, 1>(a, s, ws & 4);
-  return launch_conv_cfg<8, 64, 2, 2>(a, s, ws & 8);
+  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) return launch_conv_cfg<16, 128, 2, 2>(a, s);
+  if (px32 * (a.Cout / 64) >= 512) return launch_conv_cfg<32, 64, 4, 1>(a, s);      // 512 px x 64 ch
+  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_conv_cfg<16, 128, 2, 2>(a, s);
+  if (px16 * (a.Cout / 64) >= 256) return launch_conv_cfg<16, 64, 4, 1>(a, s);
+  return launch_conv_cfg<8, 64, 2, 2>(a, s);
 }
 
 // ---------------------------------------------------------------------------
