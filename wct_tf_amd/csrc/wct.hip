@@ -3,8 +3,8 @@
 // Feature maps stay pixel-major (NHWC flattened: X[n][c], fp32) so none of the
 // reference's four transposes exist.  Per transform:
 //   K3  colstats      per-channel mean (two-stage, deterministic)
-//   K4  cov           C x C covariance of the centred features, split-K on
-//                     v_mfma_f32_32x32x2_f32 (exact fp32), mean subtracted at load
+//   K4  cov           C x C covariance of the centred features, split-K; operands split into fp16
+//                     hi+lo pairs (22 bits) on v_mfma_f32_32x32x16_f16, mean subtracted at load
 //   K5  jacobi        batched two-sided block-Jacobi eigensolver (content+style together)
 //   K6  tbuild        T = E_s f_s(L_s) E_s^T . E_c f_c(L_c) E_c^T with the 1e-5 cut-off
 //   K7  apply         out = (x - mc) M^T + b,  M = alpha T + (1-alpha) I  (one GEMM,
@@ -24,6 +24,7 @@ struct StatArgs {
   int n[2];
   const float* mean;     // [2P][C] or null; if set, accumulate (x-mean)^2 instead of x
   float* partial;        // [2P][nslab][C]
+  float* absmax;         // [2P][nslab] max |x| of the slab (first pass only) or null
   int C, nslab;
 };
 
@@ -42,11 +43,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(StatArgs p) {
   const float* x = p.x[b] + (size_t)pair * N * C;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   f32x4 m = {0.f, 0.f, 0.f, 0.f};
+  float amax = 0.f;
   if (p.mean) m = *reinterpret_cast<const f32x4*>(p.mean + mat * C + c4 * 4);
   if (rp < nrp) {
     for (int r = r0 + rp; r < r1; r += nrp) {
       f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + c4 * 4);
-      if (p.mean) { v -= m; acc += v * v; } else acc += v;
+      if (p.mean) { v -= m; acc += v * v; }
+      else {
+        acc += v;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+      }
     }
   }
   red[tid] = acc;
@@ -54,6 +60,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(StatArgs p) {
   if (rp == 0) {
     for (int j = 1; j < nrp; ++j) acc += red[j * cq + c4];
     *reinterpret_cast<f32x4*>(p.partial + ((size_t)mat * p.nslab + slab) * C + c4 * 4) = acc;
+  }
+  if (p.absmax) {                            // block max (max is order-independent: deterministic)
+    __syncthreads();
+    float* redf = reinterpret_cast<float*>(red);
+    redf[tid] = amax;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (tid < st) redf[tid] = fmaxf(redf[tid], redf[tid + st]);
+      __syncthreads();
+    }
+    if (tid == 0) p.absmax[(size_t)mat * p.nslab + slab] = redf[0];
+  }
+}
+
+// scale[m] = 2^k with 2 * max|x| * 2^k in [8192, 16384): the centred features |x - mean| <= 2 max|x| then
+// sit well inside the fp16 range, whatever the range of the fp32 input (1 if the input is all zero)
+__global__ void cov_scale_kernel(const float* absmax, float* scale, int nslab) {
+  const int mat = blockIdx.x;
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nslab; i += 64) m = fmaxf(m, absmax[(size_t)mat * nslab + i]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (threadIdx.x == 0) {
+    float sc = 1.f;
+    if (m > 0.f && m < 1e30f) {
+      int e;
+      frexpf(2.f * m, &e);                   // 2m = f * 2^e, f in [0.5, 1)
+      sc = ldexpf(1.f, 14 - e);
+    }
+    scale[mat] = sc;
   }
 }
 
@@ -236,17 +271,181 @@ static int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s) {
   return WCT_OK;
 }
 
-// cov[b] = sum_split partial / (N_b - 1) + eps I
-__global__ void cov_finish_kernel(const float* partial, float* cov, int C, int nsplit, float inv0, float inv1, float eps) {
+// ---------------------------------------------------------------------------
+// K4: covariance partials  S[i][j] = sum_n (x[n][i]-m_i)(x[n][j]-m_j) s^2  on the fp16 MFMA pipe with
+// split operands.  Every centred, scaled fp32 value v is split as v = hi + lo, hi = fp16(v),
+// lo = fp16(v - hi) (the subtraction is exact): 22 significand bits, and hi*hi + hi*lo + lo*hi is
+// accumulated in fp32 by three v_mfma_f32_32x32x16_f16 (the dropped lo*lo term is 2^-22 relative).  That
+// is fp32-product accuracy at 3/16 of the fp32-MFMA time (v_mfma_f32_32x32x2_f32: 64 cycles for K=2).
+// s is a power of two per matrix (cov_scale_kernel) so no fp32 input can leave the fp16 range.
+// Only tiles on or above the diagonal are computed (cov_finish_kernel mirrors); a diagonal tile stages
+// its operand once.  Block = BT x BT tile, 256 threads = 2x2 waves; K-stage = 32 pixels.
+// LDS operand image: [channel][32 k] fp16 = 64-B rows, 16-B pieces XOR-swizzled as in the conv kernel.
+// ---------------------------------------------------------------------------
+struct CovArgs {
+  const float* x[2];     // content base [P][Nc][C], style base [P][Ns][C]
+  int n[2];
+  const float* mean;     // [2P][C]
+  const float* scale;    // [2P]
+  float* partial;        // [2P][nsplit][C][C]
+  int C, ksplit, nsplit, ntile;   // ntile = tiles per side
+};
+
+template <int BT>
+__global__ __launch_bounds__(256, 2) void cov_f16x2_kernel(CovArgs p) {
+  constexpr int TM = BT / 64;                  // 32x32 MFMA tiles per wave and side
+  constexpr int KPT = BT * 32 / 256;           // k values staged per thread and operand (16 or 8)
+  constexpr int NPC = KPT / 8;                 // 16-B pieces per thread and operand half
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4][BT * 64];   // A hi, A lo, B hi, B lo
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // upper-triangular tile index -> (ti <= tj)
+  int ti = 0, rem = blockIdx.x;
+  while (rem >= p.ntile - ti) { rem -= p.ntile - ti; ++ti; }
+  const int tj = ti + rem;
+  const bool diag = ti == tj;
+  const int m0 = ti * BT, n0 = tj * BT;
+  const int mat = blockIdx.z, split = blockIdx.y;
+  const int side = mat & 1, pair = mat >> 1;
+  const int N = p.n[side], C = p.C;
+  const float* x = p.x[side] + (size_t)pair * N * C;
+  const int kbeg = split * p.ksplit;
+  const int kend = min(N, kbeg + p.ksplit);
+  const float sc = p.scale[mat];
+
+  // staging role: channel c of the tile, k-group kg (wave-uniform).  Loads go through a buffer resource
+  // (32-bit lane offset + scalar row offset, rows past N read 0, no branches around the loads).  Rows past
+  // the slice end get a zero scale (scalar select), so they contribute exactly 0; channels past C (ragged
+  // tile) produce values that the store mask drops.
+  const int c = tid % BT;
+  const int kg = __builtin_amdgcn_readfirstlane(tid / BT);
+  const float mean_a = p.mean[mat * C + min(m0 + c, C - 1)];
+  const float mean_b = p.mean[mat * C + min(n0 + c, C - 1)];
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)N * C * 4), 0x00020000);
+  const int voff_a = min(m0 + c, C - 1) * 4, voff_b = min(n0 + c, C - 1) * 4;
+
+  f32x16 acc[TM][TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto load = [&](float (&r)[KPT], int voff, int k0) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      r[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (k0 + kg * KPT + j) * C * 4, 0));
+  };
+  // split (x - mean) * s into fp16 hi + lo and park the 16-B pieces in the swizzled LDS image
+  // (`tail`: the stage straddles the slice end; rows past it get a zero scale -- a uniform select that only
+  //  the last stage of a slice pays for)
+  auto split_store = [&](const float (&r)[KPT], float mean, int k0, bool tail, unsigned char* hi, unsigned char* lo) {
+#pragma unroll
+    for (int q = 0; q < NPC; ++q) {
+      half8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s_in = (!tail || k0 + kg * KPT + q * 8 + j < kend) ? sc : 0.f;
+        const float v = (r[q * 8 + j] - mean) * s_in;
+        h[j] = (half_t)v;
+        l[j] = (half_t)(v - (float)h[j]);
+      }
+      const int chunk = kg * NPC + q;          // 16-B piece (8 k values) within the 64-B row
+      const int off = (c * 4 + (chunk ^ ((c >> 2) & 3))) * 16;
+      *reinterpret_cast<half8*>(hi + off) = h;
+      *reinterpret_cast<half8*>(lo + off) = l;
+    }
+  };
+  auto mma_stage = [&](const unsigned char* bh, const unsigned char* bl) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = ks * 2 + (lane >> 5);
+      half8 ah[TM], al[TM], bhf[TM], blf[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = (wm * TM + i) * 32 + (lane & 31);
+        const int off = (r * 4 + (chunk ^ ((r >> 2) & 3))) * 16;
+        ah[i] = *reinterpret_cast<const half8*>(lds[0] + off);
+        al[i] = *reinterpret_cast<const half8*>(lds[1] + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int r = (wn * TM + j) * 32 + (lane & 31);
+        const int off = (r * 4 + (chunk ^ ((r >> 2) & 3))) * 16;
+        bhf[j] = *reinterpret_cast<const half8*>(bh + off);
+        blf[j] = *reinterpret_cast<const half8*>(bl + off);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bhf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], blf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bhf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  float ra[KPT], rb[KPT];
+  if (diag) {                                  // one operand: the tile is its own transpose partner
+    if (kbeg < kend) load(ra, voff_a, kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+      if (k0 + 32 <= kend) split_store(ra, mean_a, k0, false, lds[0], lds[1]);
+      else split_store(ra, mean_a, k0, true, lds[0], lds[1]);
+      __syncthreads();
+      if (k0 + 32 < kend) load(ra, voff_a, k0 + 32);
+      mma_stage(lds[0], lds[1]);
+      __syncthreads();
+    }
+  } else {
+    if (kbeg < kend) { load(ra, voff_a, kbeg); load(rb, voff_b, kbeg); }
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+      if (k0 + 32 <= kend) {
+        split_store(ra, mean_a, k0, false, lds[0], lds[1]);
+        split_store(rb, mean_b, k0, false, lds[2], lds[3]);
+      } else {
+        split_store(ra, mean_a, k0, true, lds[0], lds[1]);
+        split_store(rb, mean_b, k0, true, lds[2], lds[3]);
+      }
+      __syncthreads();
+      if (k0 + 32 < kend) { load(ra, voff_a, k0 + 32); load(rb, voff_b, k0 + 32); }
+      mma_stage(lds[2], lds[3]);
+      __syncthreads();
+    }
+  }
+
+  // reg r of a tile = row (r&3)+8*(r>>2)+4*(lane>>5), col lane&31
+  float* out = p.partial + ((size_t)mat * p.nsplit + split) * C * C;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int gn = n0 + (wn * TM + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm < C && gn < C) out[(size_t)gm * C + gn] = acc[i][j][r];
+      }
+    }
+}
+
+// cov[m] = sum_split partial / (scale_m^2 (N_m - 1)) + eps I; entries below the diagonal tiles are the
+// mirror of the computed upper tiles (BT = tile side of the partials)
+__global__ void cov_finish_kernel(const float* partial, const float* scale, float* cov, int C, int nsplit, int BT,
+                                  float inv0, float inv1, float eps) {
   const int mat = blockIdx.y;             // 2*pair + side
   const size_t cc = (size_t)C * C;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= cc) return;
+  const int r = (int)(i / C), c = (int)(i % C);
+  const size_t src = (r / BT > c / BT) ? (size_t)c * C + r : i;
   const float* pb = partial + (size_t)mat * nsplit * cc;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += pb[(size_t)k * cc + i];
-  s *= ((mat & 1) == 0 ? inv0 : inv1);
-  if (i / C == i % C) s += eps;
+  for (int k = 0; k < nsplit; ++k) s += pb[(size_t)k * cc + src];
+  const float sc = scale[mat];
+  s *= ((mat & 1) == 0 ? inv0 : inv1) / (sc * sc);
+  if (r == c) s += eps;
   cov[(size_t)mat * cc + i] = s;
 }
 
@@ -765,7 +964,7 @@ __global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WctCarve {
-  float *mean, *var, *stat_partial, *cov_partial, *A, *V, *d, *Tw, *Tcs, *T, *M, *bias;
+  float *mean, *var, *stat_partial, *absmax, *scale, *cov_partial, *A, *V, *d, *Tw, *Tcs, *T, *M, *bias;
   void* jacobi_ws; size_t jacobi_bytes;
   int nslab, nsplit, ksplit;
   size_t total;
@@ -774,11 +973,14 @@ struct WctCarve {
 static int wct_nslab(int N) { int s = cdiv(N, 64); return s < 1 ? 1 : (s > 256 ? 256 : s); }
 
 static void cov_split(int C, int Nmax, int P, int* nsplit, int* ksplit) {
-  const int tiles = (C >= 128 ? (C / 128) * (C / 128) : 1) * P;
-  int want = 128 / tiles;                      // x2 matrices per pair: one block per CU at P = 1, more with P
+  const int nt = C >= 128 ? cdiv(C, 128) : 1;
+  const int tiles = nt * (nt + 1) / 2 * P;     // tiles on or above the diagonal
+  // slices per matrix: x2 matrices per pair.  A single pair gets >= 64 blocks (its covariance is a few tens
+  // of microseconds either way); a finer split only multiplies the partial-sum traffic of a large batch
+  int want = 32 / tiles;
   if (want < 1) want = 1;
-  int ks = cdiv(cdiv(Nmax, want), GK) * GK;
-  if (ks < 256) ks = 256;       // multiple of GK = 32
+  int ks = cdiv(cdiv(Nmax, want), 32) * 32;    // multiple of the kernel's K-stage
+  if (ks < 256) ks = 256;
   *ksplit = ks;
   *nsplit = cdiv(Nmax, ks);
 }
@@ -795,6 +997,8 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   w.mean = (float*)take((size_t)2 * P * C * sizeof(float));
   w.var = (float*)take((size_t)2 * P * C * sizeof(float));
   w.stat_partial = (float*)take((size_t)2 * P * w.nslab * C * sizeof(float));
+  w.absmax = (float*)take((size_t)2 * P * w.nslab * sizeof(float));
+  w.scale = (float*)take((size_t)2 * P * sizeof(float));
   w.cov_partial = (float*)take((size_t)2 * P * w.nsplit * cc);
   w.A = (float*)take(2 * P * cc);
   w.V = (float*)take(2 * P * cc);
@@ -818,11 +1022,12 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
                         const WctCarve& w, bool with_var, hipStream_t s) {
   StatArgs sa;
   sa.x[0] = content; sa.x[1] = style; sa.n[0] = Nc; sa.n[1] = Ns;
-  sa.mean = nullptr; sa.partial = w.stat_partial; sa.C = C; sa.nslab = w.nslab;
+  sa.mean = nullptr; sa.partial = w.stat_partial; sa.absmax = w.absmax; sa.C = C; sa.nslab = w.nslab;
   hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
   hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.mean, C, w.nslab, (float)Nc, (float)Ns);
+  hipLaunchKernelGGL(cov_scale_kernel, dim3(2 * P), dim3(64), 0, s, w.absmax, w.scale, w.nslab);
   if (with_var) {
-    sa.mean = w.mean;
+    sa.mean = w.mean; sa.absmax = nullptr;
     hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.var, C, w.nslab, (float)Nc, (float)Ns);
   }
@@ -843,26 +1048,23 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   if (stages & WCT_STAGE_COV) {
   if ((rc = launch_means(content, Nc, style, Ns, C, P, w, false, s))) return rc;
 
-  // covariance partials: matrix 2p+side, side 0 = content, 1 = style
-  for (int b = 0; b < 2; ++b) {
-    GemmArgs g = {};
-    const float* x = b == 0 ? content : style;
-    const int N = b == 0 ? Nc : Ns;
-    g.A = x; g.lda = C; g.a_kmajor = 1; g.B = x; g.ldb = C; g.b_kmajor = 1;
-    g.sA = g.sB = (size_t)N * C;
-    g.a_sub_m = w.mean + b * C; g.b_sub_n = w.mean + b * C; g.s_sub_m = g.s_sub_n = 2 * (size_t)C;
-    g.M = C; g.N = C; g.K = N; g.ksplit = w.ksplit;
-    g.out32 = w.cov_partial + (size_t)b * w.nsplit * cc; g.ldo = C; g.out_split_stride = cc;
-    g.s_out = 2 * (size_t)w.nsplit * cc;
-    // slices past this side's K write zeros (kbeg >= kend leaves acc = 0), keeping the reduction uniform
-    if ((rc = launch_gemm(g, w.nsplit, P, s))) return rc;
+  // covariance partials: matrix 2p+side, side 0 = content, 1 = style; slices past a side's N write zeros
+  const int BT = C >= 128 ? 128 : 64;
+  {
+    CovArgs ca;
+    ca.x[0] = content; ca.x[1] = style; ca.n[0] = Nc; ca.n[1] = Ns;
+    ca.mean = w.mean; ca.scale = w.scale; ca.partial = w.cov_partial;
+    ca.C = C; ca.ksplit = w.ksplit; ca.nsplit = w.nsplit; ca.ntile = cdiv(C, BT);
+    dim3 grid(ca.ntile * (ca.ntile + 1) / 2, w.nsplit, 2 * P);
+    if (BT == 128) hipLaunchKernelGGL((cov_f16x2_kernel<128>), grid, dim3(256), 0, s, ca);
+    else hipLaunchKernelGGL((cov_f16x2_kernel<64>), grid, dim3(256), 0, s, ca);
   }
   // eps_in < 0 selects the reference defaults: 1e-8 on the covariance diagonal for wct_tf
   // (ops.py:24,45,50), 1e-5 inside the spectral gains for wct_np (ops.py:92,114,127)
   const float eps_user = eps_in >= 0.f ? eps_in : (mode == WCT_MODE_TF ? 1e-8f : 1e-5f);
   const float eps = mode == WCT_MODE_TF ? eps_user : 0.f;
   hipLaunchKernelGGL(cov_finish_kernel, dim3((unsigned)((cc + 255) / 256), 2 * P), dim3(256), 0, s,
-                     w.cov_partial, w.A, C, w.nsplit, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps);
+                     w.cov_partial, w.scale, w.A, C, w.nsplit, BT, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps);
   }
   if (stages & WCT_STAGE_EIG) {
     if (nside > 0 && P >= 2) {
