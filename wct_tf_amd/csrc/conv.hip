@@ -304,6 +304,8 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
 int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK(a.Cin % 64 == 0 && a.Cout % 64 == 0 && a.H > 1 && a.W > 1 && a.B > 0);
   ARG_CHECK(!a.upsample || (a.H % 2 == 0 && a.W % 2 == 0));
+  // one image's activations are addressed with 32-bit byte offsets (buffer loads)
+  ARG_CHECK((size_t)a.H * a.W * a.Cin * 2 < ((size_t)1 << 31));
   ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
   static const int force = getenv("WCT_CONV_CFG") ? atoi(getenv("WCT_CONV_CFG")) : 0;   // tuning switch

@@ -941,20 +941,202 @@ __global__ void spectral_gain_kernel(const float* A, float* d, int C, int mode, 
 }
 
 // M = alpha T + (1-alpha) I ; bias = alpha ms (+ (1-alpha) mc in tf mode)
-__global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo, float* bias, int C, float alpha, int mode) {
+// mabs[pair] = max |M| as float bits (zeroed by the caller; the max of non-negative floats is the max of
+// their bit patterns and does not depend on the order of the atomics)
+__global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo, float* bias, unsigned* mabs,
+                                    int C, float alpha, int mode) {
+  __shared__ float red[4];
   const int pair = blockIdx.y;
   const size_t cc = (size_t)C * C;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  float av = 0.f;
   if (i < cc) {
     float v = alpha * T[pair * cc + i];
     if (i / C == i % C) v += 1.f - alpha;
     Mo[pair * cc + i] = v;
+    av = fabsf(v);
+  }
+  for (int o = 32; o > 0; o >>= 1) av = fmaxf(av, __shfl_xor(av, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = av;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    av = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (av < 1e30f) atomicMax(mabs + pair, __float_as_uint(av));
   }
   if (i < (size_t)C) {
     const float* mp = mean + (size_t)pair * 2 * C;
     float b = alpha * mp[C + i];
     if (mode == WCT_MODE_TF) b += (1.f - alpha) * mp[i];
     bias[pair * C + i] = b;
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// K7: apply  out[n][j] = sum_k (x[n][k] - mc[k]) M[j][k] + b[j]   (ops.py:73-83 with the blend folded into M, b)
+// Same split-operand scheme as the covariance: (x - mc) s_x and M s_M are split into fp16 hi + lo and
+// multiplied by three v_mfma_f32_32x32x16_f16 with fp32 accumulation; s_x, s_M are powers of two.
+// D[channel][pixel] (A = M rows, B = pixels) so that a lane ends up with 4 consecutive channels of one
+// pixel, as in the conv epilogue.  Block = BC channels x BP pixels, 256 threads = 2x2 waves, K-stage 32.
+// ---------------------------------------------------------------------------
+struct ApplyArgs {
+  const float* x; int N; int C;     // content features [P][N][C]
+  const float* mean;                // [2P][C]: content mean of pair p at 2p
+  const float* M; const float* bias;  // [P][C][C], [P][C]
+  const float* xscale;              // [2P]: content scale of pair p at 2p
+  const unsigned* mabs;             // [P] max |M| (float bits)
+  half_t* out16; float* out32;      // [P][N][C], either may be null
+};
+
+template <int BC, int BP>
+__global__ __launch_bounds__(256, 2) void apply_f16x2_kernel(ApplyArgs p) {
+  constexpr int TM = BC / 64, TN = BP / 64;
+  constexpr int MI = BC * 4 / 256, XI = BP * 4 / 256;    // 16-B (8 k) pieces per thread and stage
+  __shared__ __attribute__((aligned(16))) unsigned char lm[2][BC * 64];   // M hi, lo
+  __shared__ __attribute__((aligned(16))) unsigned char lx[2][BP * 64];   // x hi, lo
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int pair = blockIdx.z;
+  const int n0 = blockIdx.x * BP, c0 = blockIdx.y * BC;
+  const int N = p.N, C = p.C;
+  const float* x = p.x + (size_t)pair * N * C;
+  const float* M = p.M + (size_t)pair * C * C;
+  const float* mean = p.mean + (size_t)pair * 2 * C;
+  const float sx = p.xscale[2 * pair];
+  float sM = 1.f;
+  {
+    const float m = __uint_as_float(p.mabs[pair]);
+    if (m > 0.f) { int e; frexpf(m, &e); sM = ldexpf(1.f, 14 - e); }
+  }
+
+  // staging pointers (rows clamped: out-of-range rows are computed on valid data and dropped at the store)
+  const float* mp[MI]; const float* xp[XI];
+  int moff[MI], xoff[XI], xk[XI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int item = tid + i * 256, row = item >> 2, kq = item & 3;
+    mp[i] = M + (size_t)min(c0 + row, C - 1) * C + kq * 8;
+    moff[i] = (row * 4 + (kq ^ ((row >> 2) & 3))) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int item = tid + i * 256, row = item >> 2, kq = item & 3;
+    xp[i] = x + (size_t)min(n0 + row, N - 1) * C + kq * 8;
+    xoff[i] = (row * 4 + (kq ^ ((row >> 2) & 3))) * 16;
+    xk[i] = kq * 8;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 rm[MI][2], rx[XI][2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      rm[i][0] = *reinterpret_cast<const f32x4*>(mp[i] + k0);
+      rm[i][1] = *reinterpret_cast<const f32x4*>(mp[i] + k0 + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      rx[i][0] = *reinterpret_cast<const f32x4*>(xp[i] + k0) - *reinterpret_cast<const f32x4*>(mean + k0 + xk[i]);
+      rx[i][1] = *reinterpret_cast<const f32x4*>(xp[i] + k0 + 4) - *reinterpret_cast<const f32x4*>(mean + k0 + xk[i] + 4);
+    }
+  };
+  auto split_store = [&](const f32x4 (&r)[2], float sc, unsigned char* hi, unsigned char* lo, int off) {
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = r[j >> 2][j & 3] * sc;
+      h[j] = (half_t)v;
+      l[j] = (half_t)(v - (float)h[j]);
+    }
+    *reinterpret_cast<half8*>(hi + off) = h;
+    *reinterpret_cast<half8*>(lo + off) = l;
+  };
+
+  load(0);
+  for (int k0 = 0; k0 < C; k0 += 32) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) split_store(rm[i], sM, lm[0], lm[1], moff[i]);
+#pragma unroll
+    for (int i = 0; i < XI; ++i) split_store(rx[i], sx, lx[0], lx[1], xoff[i]);
+    __syncthreads();
+    if (k0 + 32 < C) load(k0 + 32);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = ks * 2 + (lane >> 5);
+      half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = (wm * TM + i) * 32 + (lane & 31);
+        const int off = (r * 4 + (chunk ^ ((r >> 2) & 3))) * 16;
+        ah[i] = *reinterpret_cast<const half8*>(lm[0] + off);
+        al[i] = *reinterpret_cast<const half8*>(lm[1] + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int r = (wn * TN + j) * 32 + (lane & 31);
+        const int off = (r * 4 + (chunk ^ ((r >> 2) & 3))) * 16;
+        bh[j] = *reinterpret_cast<const half8*>(lx[0] + off);
+        bl[j] = *reinterpret_cast<const half8*>(lx[1] + off);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: reg r of a tile = channel (r&3)+8*(r>>2)+4*(lane>>5), pixel lane&31
+  const float inv = 1.f / (sx * sM);
+  const float* bias = p.bias + (size_t)pair * C;
+  const int kgrp = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool n_ok = n < N;
+    const size_t row = ((size_t)pair * N + (n_ok ? n : 0)) * C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int cb = c0 + (wm * TM + i) * 32;
+      unsigned pk[4][2];
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int co = cb + 8 * rq + 4 * kgrp;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (co < C) bv = *reinterpret_cast<const f32x4*>(bias + co);
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][rq * 4 + q] * inv + bv[q];
+        if (p.out32 && n_ok && co < C) *reinterpret_cast<f32x4*>(p.out32 + row + co) = v;
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 lo = {(half_t)v[0], (half_t)v[1]}, hi = {(half_t)v[2], (half_t)v[3]};
+        pk[rq][0] = __builtin_bit_cast(unsigned, lo);
+        pk[rq][1] = __builtin_bit_cast(unsigned, hi);
+      }
+      if (p.out16) {
+        // pair register quads across the two half-waves (v_permlane32_swap): 16-B stores of 8 channels
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          auto sxw = __builtin_amdgcn_permlane32_swap(pk[2 * m][0], pk[2 * m + 1][0], false, false);
+          auto syw = __builtin_amdgcn_permlane32_swap(pk[2 * m][1], pk[2 * m + 1][1], false, false);
+          u32x4 o = {sxw[0], syw[0], sxw[1], syw[1]};
+          const int co = cb + 16 * m + 8 * kgrp;
+          if (n_ok && co < C) *reinterpret_cast<u32x4*>(p.out16 + row + co) = o;
+        }
+      }
+    }
   }
 }
 
@@ -965,6 +1147,7 @@ static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WctCarve {
   float *mean, *var, *stat_partial, *absmax, *scale, *cov_partial, *A, *V, *d, *Tw, *Tcs, *T, *M, *bias;
+  unsigned* mabs;
   void* jacobi_ws; size_t jacobi_bytes;
   int nslab, nsplit, ksplit;
   size_t total;
@@ -1008,6 +1191,7 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   w.T = (float*)take(P * cc);
   w.M = (float*)take(P * cc);
   w.bias = (float*)take((size_t)P * C * sizeof(float));
+  w.mabs = (unsigned*)take((size_t)P * sizeof(unsigned));
   w.jacobi_bytes = jacobi_workspace_bytes(C, 2 * P) + 4 * (1024 + 64 * sizeof(JacobiState));   // up to 4 groups
   w.jacobi_ws = take(w.jacobi_bytes);
   w.total = off;
@@ -1041,6 +1225,8 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
                const hipEvent_t* ev_join) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && Nc >= 2 && Ns >= 2 && P >= 1 && P <= 32);
   ARG_CHECK(mode == WCT_MODE_NP || mode == WCT_MODE_TF);
+  // the covariance kernel addresses one feature map through a buffer resource with 32-bit byte offsets
+  ARG_CHECK((size_t)Nc * C * 4 < ((size_t)1 << 31) && (size_t)Ns * C * 4 < ((size_t)1 << 31));
   WctCarve w = carve(workspace, C, Nc, Ns, P);
   ARG_CHECK(workspace_bytes >= w.total);
   int rc;
@@ -1116,16 +1302,14 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
     g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = w.T; g.ldo = C; g.s_out = cc;
     if ((rc = launch_gemm(g, 1, P, s))) return rc;
   }
-  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)((cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, C, alpha, mode);
+  HIP_TRY(hipMemsetAsync(w.mabs, 0, (size_t)P * sizeof(unsigned), s));
+  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)((cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, w.mabs, C, alpha, mode);
   {  // out[n][j] = sum_k (x[n][k]-mc[k]) M[j][k] + bias[j]
-    GemmArgs g = {};
-    g.A = content; g.lda = C; g.a_kmajor = 0; g.sA = (size_t)Nc * C;
-    g.a_sub_k = w.mean; g.s_sub_k = 2 * (size_t)C;
-    g.B = w.M; g.ldb = C; g.b_kmajor = 0; g.sB = cc;
-    g.M = Nc; g.N = C; g.K = C; g.ksplit = C;
-    g.out32 = out32; g.out16 = out16; g.ldo = C; g.s_out = (size_t)Nc * C;
-    g.bias_n = w.bias; g.s_bias = C;
-    if ((rc = launch_gemm(g, 1, P, s))) return rc;
+    ApplyArgs a;
+    a.x = content; a.N = Nc; a.C = C; a.mean = w.mean; a.M = w.M; a.bias = w.bias;
+    a.xscale = w.scale; a.mabs = w.mabs; a.out16 = out16; a.out32 = out32;
+    if (C >= 128) hipLaunchKernelGGL((apply_f16x2_kernel<128, 128>), dim3(cdiv(Nc, 128), cdiv(C, 128), P), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((apply_f16x2_kernel<64, 128>), dim3(cdiv(Nc, 128), cdiv(C, 64), P), dim3(256), 0, s, a);
   }
   HIP_TRY(hipGetLastError());
   return WCT_OK;
