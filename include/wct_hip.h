@@ -52,7 +52,7 @@ int  wct_device_count(int* n);
 
 /* ---- weights: replace vgg_from_t7 (vgg_normalised.py:10-55) and the per-decoder
  * Saver.restore (wct.py:46-58).  The library copies, folds the 1x1 'preprocess'
- * into conv1_1 and repacks to its fp16 [Cout][tap][Cin] layout.
+ * into conv1_1 and repacks to its fp16 MFMA-fragment layout [Cout/32][tap][Cin/16][lane][8].
  *   pre_w [3][3] (in,out) and pre_b [3]: the 1x1 preprocess conv;
  *   w[i] HWIO 3x3 and b[i] for conv1_1, conv1_2, conv2_1, conv2_2, conv3_1..3_4,
  *   conv4_1..4_4, conv5_1 (13 layers). */

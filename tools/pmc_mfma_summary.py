@@ -12,12 +12,12 @@ for k, v in d.items():
     if act <= 0 or 'SQ_VALU_MFMA_BUSY_CYCLES' not in v:
         continue
     wc = max(v.get('SQ_WAVE_CYCLES', (0, 1))[1], 1)
-    rows.append((act, k, v['GRBM_GUI_ACTIVE'][0], v['SQ_VALU_MFMA_BUSY_CYCLES'][1] / (act * 1024),
+    rows.append((act, k, v['GRBM_GUI_ACTIVE'][0], v['SQ_VALU_MFMA_BUSY_CYCLES'][1] / (act / 8 * 1024),
                  v.get('SQ_WAIT_ANY', (0, 0))[1] / wc, v.get('SQ_ACTIVE_INST_ANY', (0, 0))[1] / wc))
 rows.sort(reverse=True)
 with open(out_path, 'w') as f:
     f.write('# %s\n' % desc)
-    f.write('# mfma_util = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE) * 1024 SIMDs); wait / issue = fractions of SQ_WAVE_CYCLES\n')
+    f.write('# GRBM_GUI_ACTIVE is summed over the 8 XCDs: mfma_util = sum(SQ_VALU_MFMA_BUSY_CYCLES) / (sum(GRBM_GUI_ACTIVE)/8 * 1024 SIMDs); wait / issue = fractions of SQ_WAVE_CYCLES\n')
     f.write('kernel,launches,gpu_active_cycles,mfma_util,wave_wait_frac,wave_issue_frac\n')
     for act, k, n, u, wa, ai in rows[:16]:
         f.write('"%s",%d,%.4g,%.3f,%.3f,%.3f\n' % (k, n, act, u, wa, ai))

@@ -948,20 +948,20 @@ __global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo
   __shared__ float red[4];
   const int pair = blockIdx.y;
   const size_t cc = (size_t)C * C;
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;      // first element; the grid strides over the matrix
   float av = 0.f;
-  if (i < cc) {
-    float v = alpha * T[pair * cc + i];
-    if (i / C == i % C) v += 1.f - alpha;
-    Mo[pair * cc + i] = v;
-    av = fabsf(v);
+  for (size_t e = i; e < cc; e += (size_t)gridDim.x * blockDim.x) {
+    float v = alpha * T[pair * cc + e];
+    if (e / C == e % C) v += 1.f - alpha;
+    Mo[pair * cc + e] = v;
+    av = fmaxf(av, fabsf(v));
   }
   for (int o = 32; o > 0; o >>= 1) av = fmaxf(av, __shfl_xor(av, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = av;
   __syncthreads();
   if (threadIdx.x == 0) {
     av = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (av < 1e30f) atomicMax(mabs + pair, __float_as_uint(av));
+    if (av < 1e30f) atomicMax(mabs + pair, __float_as_uint(av));       // one atomic per block
   }
   if (i < (size_t)C) {
     const float* mp = mean + (size_t)pair * 2 * C;
@@ -1303,7 +1303,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
     if ((rc = launch_gemm(g, 1, P, s))) return rc;
   }
   HIP_TRY(hipMemsetAsync(w.mabs, 0, (size_t)P * sizeof(unsigned), s));
-  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)((cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, w.mabs, C, alpha, mode);
+  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)(cc >= 16384 ? 16 : (cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, w.mabs, C, alpha, mode);
   {  // out[n][j] = sum_k (x[n][k]-mc[k]) M[j][k] + bias[j]
     ApplyArgs a;
     a.x = content; a.N = Nc; a.C = C; a.mean = w.mean; a.M = w.M; a.bias = w.bias;
