@@ -90,6 +90,9 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='independent content/style pairs per GPU per step')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--alpha', type=float, default=0.8)
+    ap.add_argument('--shared-style', action='store_true',
+                    help='NOT the headline metric: every pair of a step uses ONE style image (fixed-style video, '
+                         'WCT_FLAG_STYLE_SHARED): the style side runs once per step instead of once per frame')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='no per-class HIP-event timing inside the timed region')
     args = ap.parse_args()
@@ -121,6 +124,8 @@ def main():
     lo, hi = shard_range(total_pairs, world, rank)                         # contiguous shard of the global batch
     content = np.stack([synthetic_image(1000 + i, S, S) for i in range(lo, hi)])
     style = np.stack([synthetic_image(2000 + i, S, S) for i in range(lo, hi)])
+    if args.shared_style:
+        style = style[0]
     dev = torch.device('cuda', local_rank)
     d_content = torch.from_numpy(content).to(dev)                          # inputs resident in HBM
     d_style = torch.from_numpy(style).to(dev)
@@ -131,7 +136,7 @@ def main():
 
     def step():
         ctx.stylize_batch_dev(C.c_void_p(d_content.data_ptr()), S, S, C.c_void_p(d_style.data_ptr()), S, S,
-                              B, LEVELS, args.alpha, C.c_void_p(d_out.data_ptr()))
+                              B, LEVELS, args.alpha, C.c_void_p(d_out.data_ptr()), shared_style=args.shared_style)
         if world > 1:
             ctx.sync()                                                     # library stream -> torch stream hand-off
             frames = gather_frames(d_out, world, rank)
@@ -172,7 +177,8 @@ def main():
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': 'configs[2]: full 5-level relu5_1->relu1_1, %dx%d content+style, alpha %.1f, '
-                                   'wct_tf semantics, style features recomputed per frame' % (S, S, args.alpha),
+                                   'wct_tf semantics, %s' % (S, S, args.alpha, 'ONE style per step (fixed-style video mode, not the headline '
+                                   'metric)' if args.shared_style else 'style features recomputed per frame'),
                        'pairs_per_gpu_per_step': B, 'global_batch': total_pairs,
                        'parallelism': 'pairs sharded over %d GPU(s), RCCL gather of uint8 frames' % world,
                        'weights': 'synthetic He-normal seed 42 (no pre-trained weights offline)'},

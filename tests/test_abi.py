@@ -102,6 +102,22 @@ def test_cli_flags_match_reference_and_utils(tmp_path):
     assert np.array_equal(utils.get_img(p), img)
 
 
+def test_video_cli_flags_match_reference(tmp_path):
+    from wct_tf_amd.stylize_video import build_parser, list_frames
+    from wct_tf_amd import utils
+    flags = {a for act in build_parser()._actions for a in act.option_strings}
+    for f in ['--checkpoints', '--relu-targets', '--vgg-path', '--in-path', '--out-path', '--style-path', '--tmp-dir',
+              '--keep-tmp', '--keep-colors', '--style-size', '--crop-size', '--content-size', '--passes', '--device',
+              '--alpha', '--concat', '--swap5', '--ss-alpha', '--ss-patch-size', '--ss-stride']:
+        assert f in flags, f                                   # stylize_video.py:16-41
+    # ffmpeg numbers frames frame_%d.png (stylize_video.py:76): order them numerically, not lexically
+    img = np.zeros((4, 4, 3), np.uint8)
+    for i in (10, 2, 1, 11):
+        utils.save_img(str(tmp_path / ('frame_%d.png' % i)), img)
+    assert [os.path.basename(f) for f in list_frames(str(tmp_path))] == \
+        ['frame_1.png', 'frame_2.png', 'frame_10.png', 'frame_11.png']
+
+
 def test_t7_reader_matches_reference_torchfile():
     """wct_tf_amd/t7.py on tests/golden/tiny_vgg.t7 == what the reference's torchfile.py + the
     vgg_normalised.py:22-34 walk extracted from the same file (fixture made by oracle/make_golden.py)."""

@@ -307,3 +307,49 @@ def test_abi_error_paths_on_gpu(ctx):
         fresh.close()
     with pytest.raises(WCTHipError):
         Context(99)                                           # no such device
+
+
+@pytest.mark.parametrize('adain,swap5', [(False, False), (True, False), (False, True)])
+def test_shared_style_batch_equals_per_pair(ctx, weights, adain, swap5):
+    """WCT_FLAG_STYLE_SHARED (one style for all frames of a batch: the video loop, stylize_video.py:112-121):
+    the style encoder pass, statistics and eigensystems run once per call -- and every frame must equal the
+    frame the per-pair path produces with that style, bit for bit."""
+    targets = ['relu5_1', 'relu3_1', 'relu1_1'] if swap5 else ['relu4_1', 'relu2_1', 'relu1_1']
+    B = 5
+    frames = np.stack([synthetic_image(300 + i, 64, 48) for i in range(B)])
+    style = synthetic_image(400, 56, 72)
+    if swap5:
+        ctx.set_style_swap(0.6, 3, 1)
+    shared = ctx.stylize_batch(frames, style, targets, alpha=0.7, adain=adain, swap5=swap5)
+    repl = ctx.stylize_batch(frames, np.stack([style] * B), targets, alpha=0.7, adain=adain, swap5=swap5)
+    assert shared.shape == repl.shape == (B, 64, 48, 3)
+    assert np.array_equal(shared, repl)
+    one = ctx.stylize(frames[3], style, targets, alpha=0.7, adain=adain, swap5=swap5)
+    assert np.array_equal(shared[3], one)
+    assert len({shared[i].tobytes() for i in range(B)}) == B          # the frames do differ
+
+
+def test_video_cli_end_to_end(tmp_path):
+    """python -m wct_tf_amd.stylize_video on a directory of frames (ffmpeg is absent): frames of two sizes, one
+    style, --concat; the written frames equal WCT.predict on the same inputs."""
+    from wct_tf_amd import utils
+    from wct_tf_amd.stylize_video import main
+    from wct_tf_amd.wct import WCT
+    targets = ['relu3_1', 'relu1_1']
+    in_dir = tmp_path / 'clip'
+    in_dir.mkdir()
+    frames = [synthetic_image(500 + i, 40, 56) for i in range(5)] + [synthetic_image(510, 32, 32)]
+    for i, f in enumerate(frames):
+        utils.save_img(str(in_dir / ('frame_%d.png' % (i + 1))), f)
+    style = synthetic_image(600, 48, 48)
+    utils.save_img(str(tmp_path / 'style.png'), style)
+    out_dir = tmp_path / 'out'
+    n = main(['--relu-targets'] + targets + ['--in-path', str(in_dir), '--style-path', str(tmp_path / 'style.png'),
+              '--out-path', str(out_dir), '--alpha', '0.8', '--synthetic-weights', '42', '--batch', '4', '--concat'])
+    assert n == 6
+    model = WCT(checkpoints=None, relu_targets=targets, vgg_path=None, weights=synthetic_weights(42, relu_targets=targets))
+    for i, f in enumerate(frames):
+        got = utils.get_img(str(out_dir / 'clip_style' / ('frame_%d.png' % (i + 1))))
+        want = model.predict(f, style, 0.8)
+        want = np.hstack([utils._imresize(style, (want.shape[0], want.shape[0])), want])
+        assert np.array_equal(got, want), i

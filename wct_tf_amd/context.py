@@ -221,12 +221,41 @@ class Context(object):
         check(self.lib.wct_d2h(self.h, arr.ctypes.data_as(C.c_void_p), src, arr.nbytes))
 
     def stylize_batch_dev(self, content_dev, hc, wc, style_dev, hs, ws, batch, relu_targets, alpha, out_dev,
-                          adain=False, wct_mode='tf'):
+                          adain=False, wct_mode='tf', swap5=False, shared_style=False):
+        """B pairs resident in HBM.  shared_style: style_dev holds ONE image used for every pair (fixed-style
+        video): its encoder pass, statistics and eigensystems run once per call; the frames are bit-identical
+        to the ones a replicated style produces."""
         lv = _levels(relu_targets)
         arr = (C.c_int * len(lv))(*lv)
-        flags = (_lib.FLAG_ADAIN if adain else 0) | (_lib.FLAG_MODE_NP if wct_mode == 'np' else 0)
+        flags = (_lib.FLAG_ADAIN if adain else 0) | (_lib.FLAG_MODE_NP if wct_mode == 'np' else 0) | \
+            (_lib.FLAG_SWAP5 if swap5 else 0) | (_lib.FLAG_STYLE_SHARED if shared_style else 0)
         check(self.lib.wct_stylize_batch_dev(self.h, content_dev, hc, wc, style_dev, hs, ws, batch, arr, len(lv),
                                              float(alpha), flags, out_dev))
+
+    def stylize_batch(self, contents_u8, style_u8, relu_targets, alpha=1.0, adain=False, wct_mode='tf', swap5=False):
+        """Host arrays in, host array out: contents [B][H][W][3] uint8 (B <= 32); style either one image
+        [Hs][Ws][3] shared by all frames or [B][Hs][Ws][3].  Returns [B][Ho][Wo][3] uint8."""
+        c = u8(contents_u8)
+        s = u8(style_u8)
+        assert c.ndim == 4 and c.shape[3] == 3 and s.ndim in (3, 4) and s.shape[-1] == 3
+        shared = s.ndim == 3
+        assert shared or s.shape[0] == c.shape[0]
+        B, hc, wc = c.shape[:3]
+        hs, ws = s.shape[-3], s.shape[-2]
+        ho, wo = self.output_size(hc, wc, relu_targets)
+        out = np.empty((B, ho, wo, 3), np.uint8)
+        dc, ds, do = self.dev_alloc(c.nbytes), self.dev_alloc(s.nbytes), self.dev_alloc(out.nbytes)
+        try:
+            self.h2d(dc, c)
+            self.h2d(ds, s)
+            self.stylize_batch_dev(dc, hc, wc, ds, hs, ws, B, relu_targets, alpha, do, adain=adain,
+                                   wct_mode=wct_mode, swap5=swap5, shared_style=shared)
+            self.sync()
+            self.d2h(out, do)
+        finally:
+            for p in (dc, ds, do):
+                self.dev_free(p)
+        return out
 
     # ---- measurement -------------------------------------------------------
     def prof_enable(self, on=True):

@@ -460,23 +460,24 @@ static int run_decoder(wct_ctx* c, int level, const half_t* feat16, int B, int h
 
 static int run_transform(wct_ctx* c, const float* fc, int Nc, const float* fs, int Ns, int C, int P,
                          float alpha, unsigned flags, float eps, half_t* out16, float* out32, int* sweeps_dev) {
+  const int shared = (flags & WCT_FLAG_STYLE_SHARED) ? 1 : 0;
   const size_t ws = wct_workspace_bytes(C, Nc, Ns, P);
   TRY(ensure(c, c->wct_ws, ws));
   if (flags & WCT_FLAG_ADAIN) {
     ProfScope ps(c, 7, 0, (double)P * (2.0 * Nc + 2.0 * Ns) * C * 4 + (double)P * Nc * C * 6);
-    return launch_adain(fc, Nc, fs, Ns, C, P, alpha, 1e-5f, out16, out32, c->wct_ws.p, c->wct_ws.cap, c->stream);
+    return launch_adain(fc, Nc, fs, Ns, C, P, alpha, 1e-5f, out16, out32, c->wct_ws.p, c->wct_ws.cap, c->stream, shared);
   }
   const int mode = (flags & WCT_FLAG_MODE_NP) ? WCT_MODE_NP : WCT_MODE_TF;
   {
     ProfScope ps(c, 4, (double)P * 2.0 * C * C * ((double)Nc + Ns), (double)P * 2.0 * ((double)Nc + Ns) * C * 4);
-    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, 0, nullptr, nullptr));
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, 0, nullptr, nullptr, shared));
   }
   {
     ProfScope ps(c, 5, 0, 0);
-    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_EIG, c->stream, c->side, c->nside, c->ev_fork, c->ev_join));
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_EIG, c->stream, c->side, c->nside, c->ev_fork, c->ev_join, shared));
   }
   ProfScope ps(c, 6, (double)P * (2.0 * C * C * Nc + 6.0 * C * C * C), (double)P * Nc * C * (4 + (out16 ? 2 : 0) + (out32 ? 4 : 0)));
-  return launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_APPLY, c->stream, nullptr, 0, nullptr, nullptr);
+  return launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_APPLY, c->stream, nullptr, 0, nullptr, nullptr, shared);
 }
 
 // ---------------------------------------------------------------------------
@@ -520,7 +521,7 @@ extern "C" int wct_adain(wct_ctx* c, const float* content, int Nc, const float* 
   TRY(ensure(c, c->stage[2], (size_t)Nc * C * 4));
   TRY(ensure(c, c->wct_ws, wct_workspace_bytes(C, Nc, Ns, 1)));
   TRY(launch_adain((float*)dc, Nc, (float*)ds, Ns, C, 1, alpha, epsilon, nullptr, (float*)c->stage[2].p,
-                   c->wct_ws.p, c->wct_ws.cap, c->stream));
+                   c->wct_ws.p, c->wct_ws.cap, c->stream, 0));
   return fetch(c, out, c->stage[2].p, (size_t)Nc * C * 4);
 }
 
@@ -702,8 +703,12 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
   int Ho, Wo;
   TRY(wct_output_size(Hc, Wc, levels, n_levels, &Ho, &Wo));
 
+  // WCT_FLAG_STYLE_SHARED: `style` is ONE image for all B pairs (a video with a fixed style); its encoder pass,
+  // statistics and eigensystems are computed once per call instead of once per pair
+  const int shared = (flags & WCT_FLAG_STYLE_SHARED) ? 1 : 0;
+  const int Bs = shared ? 1 : B;
   // images to fp32 in [0,1] (wct.py:60-64)
-  const size_t nc = (size_t)B * Hc * Wc * 3, ns = (size_t)B * Hs * Ws * 3;
+  const size_t nc = (size_t)B * Hc * Wc * 3, ns = (size_t)Bs * Hs * Ws * 3;
   TRY(ensure(c, c->img_c, nc * 4));
   TRY(ensure(c, c->img_s, ns * 4));
   {
@@ -717,10 +722,10 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
     const int l = levels[i];
     int h, w;
     level_dims(Hs, Ws, l, &h, &w);
-    TRY(ensure(c, c->feat_s[l], (size_t)B * h * w * LEVEL_C[l] * 4));
+    TRY(ensure(c, c->feat_s[l], (size_t)Bs * h * w * LEVEL_C[l] * 4));
     taps[l] = (float*)c->feat_s[l].p;
   }
-  TRY(run_encoder(c, (float*)c->img_s.p, B, Hs, Ws, 0, deepest, taps));
+  TRY(run_encoder(c, (float*)c->img_s.p, Bs, Hs, Ws, 0, deepest, taps));
 
   const float* cur = (float*)c->img_c.p;
   int H = Hc, W = Wc;
@@ -742,7 +747,7 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
       ProfScope ps(c, 7, 0, 0);
       for (int b = 0; b < B; ++b)
         TRY(launch_style_swap((float*)c->feat_c.p + (size_t)b * h * w * C, h, w,
-                              (float*)c->feat_s[l].p + (size_t)b * hs * ws * C, hs, ws, C, c->ss_alpha, c->ss_patch,
+                              (float*)c->feat_s[l].p + (size_t)(shared ? 0 : b) * hs * ws * C, hs, ws, C, c->ss_alpha, c->ss_patch,
                               c->ss_stride, -1.f, (half_t*)c->wct_out.p + (size_t)b * h * w * C, nullptr,
                               c->wct_ws.p, c->wct_ws.cap, c->stream));
     } else

@@ -90,11 +90,13 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
                float alpha, int mode, float eps /* <0: reference default */, half_t* out16, float* out32,
                void* workspace, size_t workspace_bytes, int* sweeps_dev, int stages, hipStream_t s,
                const hipStream_t* side /* optional extra streams: the eigenproblems are split over 1+nside */,
-               int nside, hipEvent_t ev_fork, const hipEvent_t* ev_join);
+               int nside, hipEvent_t ev_fork, const hipEvent_t* ev_join,
+               int shared_style /* style holds ONE feature map used by all P pairs: its statistics and
+                                   eigensystem are computed once */);
 enum { WCT_STAGE_COV = 1, WCT_STAGE_EIG = 2, WCT_STAGE_APPLY = 4, WCT_STAGE_ALL = 7 };
 int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P,
                  float alpha, float eps, half_t* out16, float* out32,
-                 void* workspace, size_t workspace_bytes, hipStream_t s);
+                 void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style);
 // Symmetric eigensolver (batched): A [nmat][C][C] is overwritten (diag -> eigenvalues),
 // V [nmat][C][C] gets eigenvectors in columns.  C multiple of 32, 32 <= C <= 1024.
 int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace,

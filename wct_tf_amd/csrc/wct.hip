@@ -19,6 +19,12 @@
 // ---------------------------------------------------------------------------
 // grid (nslab, 2P): matrix m = 2*pair + side (0 content, 1 style); slab s reduces rows
 // [s*rows_per_slab, ...) of X_m[N_side][C]
+// With a shared style (one style image for every pair of the batch: video) only pair 0's style matrix
+// (matrix 1) is computed; the style matrices of the other pairs are skipped and their consumers read pair 0's.
+__device__ __host__ __forceinline__ bool skip_style_mat(int mat, int shared_style) {
+  return shared_style && (mat & 1) && mat > 1;
+}
+
 struct StatArgs {
   const float* x[2];     // content base [P][Nc][C], style base [P][Ns][C]
   int n[2];
@@ -26,11 +32,13 @@ struct StatArgs {
   float* partial;        // [2P][nslab][C]
   float* absmax;         // [2P][nslab] max |x| of the slab (first pass only) or null
   int C, nslab;
+  int shared_style;
 };
 
 __global__ __launch_bounds__(256) void colsum_kernel(StatArgs p) {
   __shared__ f32x4 red[256];
   const int mat = blockIdx.y, slab = blockIdx.x;
+  if (skip_style_mat(mat, p.shared_style)) return;
   const int b = mat & 1, pair = mat >> 1;
   const int C = p.C, cq = C / 4;
   const int nrp = 256 / cq;                  // rows handled in parallel (C <= 1024)
@@ -76,8 +84,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(StatArgs p) {
 
 // scale[m] = 2^k with 2 * max|x| * 2^k in [8192, 16384): the centred features |x - mean| <= 2 max|x| then
 // sit well inside the fp16 range, whatever the range of the fp32 input (1 if the input is all zero)
-__global__ void cov_scale_kernel(const float* absmax, float* scale, int nslab) {
+__global__ void cov_scale_kernel(const float* absmax, float* scale, int nslab, int shared_style) {
   const int mat = blockIdx.x;
+  if (skip_style_mat(mat, shared_style)) return;
   float m = 0.f;
   for (int i = threadIdx.x; i < nslab; i += 64) m = fmaxf(m, absmax[(size_t)mat * nslab + i]);
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
@@ -93,8 +102,9 @@ __global__ void cov_scale_kernel(const float* absmax, float* scale, int nslab) {
 }
 
 // out[m][c] = sum_slab partial / denom_side
-__global__ void colsum_finish_kernel(const float* partial, float* out, int C, int nslab, float d0, float d1) {
+__global__ void colsum_finish_kernel(const float* partial, float* out, int C, int nslab, float d0, float d1, int shared_style) {
   const int mat = blockIdx.y;
+  if (skip_style_mat(mat, shared_style)) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
@@ -289,6 +299,7 @@ struct CovArgs {
   const float* scale;    // [2P]
   float* partial;        // [2P][nsplit][C][C]
   int C, ksplit, nsplit, ntile;   // ntile = tiles per side
+  int shared_style;
 };
 
 template <int BT>
@@ -306,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void cov_f16x2_kernel(CovArgs p) {
   const bool diag = ti == tj;
   const int m0 = ti * BT, n0 = tj * BT;
   const int mat = blockIdx.z, split = blockIdx.y;
+  if (skip_style_mat(mat, p.shared_style)) return;
   const int side = mat & 1, pair = mat >> 1;
   const int N = p.n[side], C = p.C;
   const float* x = p.x[side] + (size_t)pair * N * C;
@@ -433,8 +445,9 @@ __global__ __launch_bounds__(256, 2) void cov_f16x2_kernel(CovArgs p) {
 // cov[m] = sum_split partial / (scale_m^2 (N_m - 1)) + eps I; entries below the diagonal tiles are the
 // mirror of the computed upper tiles (BT = tile side of the partials)
 __global__ void cov_finish_kernel(const float* partial, const float* scale, float* cov, int C, int nsplit, int BT,
-                                  float inv0, float inv1, float eps) {
+                                  float inv0, float inv1, float eps, int shared_style) {
   const int mat = blockIdx.y;             // 2*pair + side
+  if (skip_style_mat(mat, shared_style)) return;
   const size_t cc = (size_t)C * C;
   const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (i >= cc) return;
@@ -752,12 +765,15 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
   }
 }
 
-__global__ void jacobi_init_kernel(float* V, JacobiState* st, int C) {
+// mat0 = index of the group's first matrix in the 2P batch; skipped style matrices start out `done`
+__global__ void jacobi_init_kernel(float* V, JacobiState* st, int C, int mat0, int shared_style) {
   const int m = blockIdx.y;
+  const bool skip = skip_style_mat(mat0 + m, shared_style);
   const size_t cc = (size_t)C * C;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x)
-    V[(size_t)m * cc + i] = (i / C == i % C) ? 1.f : 0.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { st[m].offmax = 0u; st[m].done = 0; st[m].sweeps = 0; st[m].pad = 0; }
+  if (!skip)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x)
+      V[(size_t)m * cc + i] = (i / C == i % C) ? 1.f : 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { st[m].offmax = 0u; st[m].done = skip ? 1 : 0; st[m].sweeps = 0; st[m].pad = 0; }
 }
 
 __global__ void jacobi_check_kernel(JacobiState* st, int nmat, float conv_tol) {
@@ -782,6 +798,7 @@ size_t jacobi_workspace_bytes(int C, int nmat) {
 // that one half's latency-bound pair problems hide under the other half's chip-wide tile update).
 struct JacobiGroup {
   float* A; float* V; int nmat; float* Qbuf; JacobiState* st; hipStream_t stream; int* sweeps_out;
+  int mat0, shared_style;      // position in a WCT batch (skip_style_mat); 0, 0 for a plain batch
 };
 
 static JacobiState* jacobi_host_flags() {
@@ -857,7 +874,8 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   JacobiState* host = jacobi_host_flags();
   hipStream_t main = grp[0].stream;
   for (int g = 0; g < ngrp; ++g)
-    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].V, grp[g].st, C);
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].V, grp[g].st, C,
+                       grp[g].mat0, grp[g].shared_style);
   hipGraphExec_t exec = nullptr;
   if (use_graph) {
     // the graph forks from / joins to the main stream: the side streams' init kernels must be ordered first
@@ -898,6 +916,7 @@ static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat
   G->A = A; G->V = V; G->nmat = nmat; G->Qbuf = reinterpret_cast<float*>(workspace);
   G->st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
   G->stream = s; G->sweeps_out = sweeps_out;
+  G->mat0 = 0; G->shared_style = 0;
   return WCT_OK;
 }
 
@@ -922,8 +941,9 @@ int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, siz
 // K6: spectral functions with the reference cut-off
 // ---------------------------------------------------------------------------
 // d[2p][k] = whitening gain of content eigenvalue k, d[2p+1][k] = colouring gain of style eigenvalue k
-__global__ void spectral_gain_kernel(const float* A, float* d, int C, int mode, float eps_np) {
+__global__ void spectral_gain_kernel(const float* A, float* d, int C, int mode, float eps_np, int shared_style) {
   const int mat = blockIdx.y;
+  if (skip_style_mat(mat, shared_style)) return;
   const int b = mat & 1;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= C) return;
@@ -944,7 +964,7 @@ __global__ void spectral_gain_kernel(const float* A, float* d, int C, int mode, 
 // mabs[pair] = max |M| as float bits (zeroed by the caller; the max of non-negative floats is the max of
 // their bit patterns and does not depend on the order of the atomics)
 __global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo, float* bias, unsigned* mabs,
-                                    int C, float alpha, int mode) {
+                                    int C, float alpha, int mode, int shared_style) {
   __shared__ float red[4];
   const int pair = blockIdx.y;
   const size_t cc = (size_t)C * C;
@@ -965,7 +985,8 @@ __global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo
   }
   if (i < (size_t)C) {
     const float* mp = mean + (size_t)pair * 2 * C;
-    float b = alpha * mp[C + i];
+    const float* ms = mean + (size_t)(shared_style ? 0 : pair) * 2 * C + C;     // style mean
+    float b = alpha * ms[i];
     if (mode == WCT_MODE_TF) b += (1.f - alpha) * mp[i];
     bias[pair * C + i] = b;
   }
@@ -1203,17 +1224,17 @@ size_t wct_workspace_bytes(int C, int Nc, int Ns, int P) {
 }
 
 static int launch_means(const float* content, int Nc, const float* style, int Ns, int C, int P,
-                        const WctCarve& w, bool with_var, hipStream_t s) {
+                        const WctCarve& w, bool with_var, int shared_style, hipStream_t s) {
   StatArgs sa;
   sa.x[0] = content; sa.x[1] = style; sa.n[0] = Nc; sa.n[1] = Ns;
-  sa.mean = nullptr; sa.partial = w.stat_partial; sa.absmax = w.absmax; sa.C = C; sa.nslab = w.nslab;
+  sa.mean = nullptr; sa.partial = w.stat_partial; sa.absmax = w.absmax; sa.C = C; sa.nslab = w.nslab; sa.shared_style = shared_style;
   hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.mean, C, w.nslab, (float)Nc, (float)Ns);
-  hipLaunchKernelGGL(cov_scale_kernel, dim3(2 * P), dim3(64), 0, s, w.absmax, w.scale, w.nslab);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.mean, C, w.nslab, (float)Nc, (float)Ns, shared_style);
+  hipLaunchKernelGGL(cov_scale_kernel, dim3(2 * P), dim3(64), 0, s, w.absmax, w.scale, w.nslab, shared_style);
   if (with_var) {
     sa.mean = w.mean; sa.absmax = nullptr;
     hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.var, C, w.nslab, (float)Nc, (float)Ns);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.var, C, w.nslab, (float)Nc, (float)Ns, shared_style);
   }
   HIP_TRY(hipGetLastError());
   return WCT_OK;
@@ -1222,7 +1243,7 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
                half_t* out16, float* out32, void* workspace, size_t workspace_bytes, int* sweeps_dev,
                int stages, hipStream_t s, const hipStream_t* side, int nside, hipEvent_t ev_fork,
-               const hipEvent_t* ev_join) {
+               const hipEvent_t* ev_join, int shared_style) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && Nc >= 2 && Ns >= 2 && P >= 1 && P <= 32);
   ARG_CHECK(mode == WCT_MODE_NP || mode == WCT_MODE_TF);
   // the covariance kernel addresses one feature map through a buffer resource with 32-bit byte offsets
@@ -1232,7 +1253,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   int rc;
   const size_t cc = (size_t)C * C;
   if (stages & WCT_STAGE_COV) {
-  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, false, s))) return rc;
+  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, false, shared_style, s))) return rc;
 
   // covariance partials: matrix 2p+side, side 0 = content, 1 = style; slices past a side's N write zeros
   const int BT = C >= 128 ? 128 : 64;
@@ -1240,7 +1261,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
     CovArgs ca;
     ca.x[0] = content; ca.x[1] = style; ca.n[0] = Nc; ca.n[1] = Ns;
     ca.mean = w.mean; ca.scale = w.scale; ca.partial = w.cov_partial;
-    ca.C = C; ca.ksplit = w.ksplit; ca.nsplit = w.nsplit; ca.ntile = cdiv(C, BT);
+    ca.C = C; ca.ksplit = w.ksplit; ca.nsplit = w.nsplit; ca.ntile = cdiv(C, BT); ca.shared_style = shared_style;
     dim3 grid(ca.ntile * (ca.ntile + 1) / 2, w.nsplit, 2 * P);
     if (BT == 128) hipLaunchKernelGGL((cov_f16x2_kernel<128>), grid, dim3(256), 0, s, ca);
     else hipLaunchKernelGGL((cov_f16x2_kernel<64>), grid, dim3(256), 0, s, ca);
@@ -1250,7 +1271,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   const float eps_user = eps_in >= 0.f ? eps_in : (mode == WCT_MODE_TF ? 1e-8f : 1e-5f);
   const float eps = mode == WCT_MODE_TF ? eps_user : 0.f;
   hipLaunchKernelGGL(cov_finish_kernel, dim3((unsigned)((cc + 255) / 256), 2 * P), dim3(256), 0, s,
-                     w.cov_partial, w.scale, w.A, C, w.nsplit, BT, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps);
+                     w.cov_partial, w.scale, w.A, C, w.nsplit, BT, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps, shared_style);
   }
   if (stages & WCT_STAGE_EIG) {
     if (nside > 0 && P >= 2) {
@@ -1274,6 +1295,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
         if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ev_fork, 0));
         if ((rc = jacobi_make_group(&grp[g], w.A + (size_t)m0 * cc, w.V + (size_t)m0 * cc, C, n, (char*)w.jacobi_ws + off,
                                     bytes, sweeps_dev ? sweeps_dev + m0 : nullptr, sg))) return rc;
+        grp[g].mat0 = m0; grp[g].shared_style = shared_style;
         off += bytes; m0 += n;
       }
       if ((rc = jacobi_dispatch(grp, ngrp, C))) return rc;
@@ -1282,28 +1304,31 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
         HIP_TRY(hipStreamWaitEvent(s, ev_join[g - 1], 0));
       }
     } else {
-      if ((rc = launch_jacobi_eigh(w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, s))) return rc;
+      JacobiGroup G;
+      if ((rc = jacobi_make_group(&G, w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, s))) return rc;
+      G.shared_style = shared_style;
+      if ((rc = jacobi_dispatch(&G, 1, C))) return rc;
     }
   }
   if (!(stages & WCT_STAGE_APPLY)) return WCT_OK;
 
-  hipLaunchKernelGGL(spectral_gain_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.A, w.d, C, mode, eps_in >= 0.f ? eps_in : 1e-5f);
+  hipLaunchKernelGGL(spectral_gain_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.A, w.d, C, mode, eps_in >= 0.f ? eps_in : 1e-5f, shared_style);
   for (int b = 0; b < 2; ++b) {   // Tw = (Vc diag dc) Vc^T ; Tcs = (Vs diag ds) Vs^T
     GemmArgs g = {};
     g.A = w.V + b * cc; g.lda = C; g.a_kmajor = 0; g.a_scale_k = w.d + b * C; g.s_scale_k = 2 * (size_t)C;
     g.B = w.V + b * cc; g.ldb = C; g.b_kmajor = 0; g.sA = g.sB = 2 * cc;
     g.M = C; g.N = C; g.K = C; g.ksplit = C;
     g.out32 = b == 0 ? w.Tw : w.Tcs; g.ldo = C; g.s_out = cc;
-    if ((rc = launch_gemm(g, 1, P, s))) return rc;
+    if ((rc = launch_gemm(g, 1, (b == 1 && shared_style) ? 1 : P, s))) return rc;     // one colouring matrix for a shared style
   }
   {
     GemmArgs g = {};   // T = Tcs . Tw
-    g.A = w.Tcs; g.lda = C; g.a_kmajor = 0; g.B = w.Tw; g.ldb = C; g.b_kmajor = 1; g.sA = g.sB = cc;
+    g.A = w.Tcs; g.lda = C; g.a_kmajor = 0; g.B = w.Tw; g.ldb = C; g.b_kmajor = 1; g.sA = shared_style ? 0 : cc; g.sB = cc;
     g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = w.T; g.ldo = C; g.s_out = cc;
     if ((rc = launch_gemm(g, 1, P, s))) return rc;
   }
   HIP_TRY(hipMemsetAsync(w.mabs, 0, (size_t)P * sizeof(unsigned), s));
-  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)(cc >= 16384 ? 16 : (cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, w.mabs, C, alpha, mode);
+  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)(cc >= 16384 ? 16 : (cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, w.mabs, C, alpha, mode, shared_style);
   {  // out[n][j] = sum_k (x[n][k]-mc[k]) M[j][k] + bias[j]
     ApplyArgs a;
     a.x = content; a.N = Nc; a.C = C; a.mean = w.mean; a.M = w.M; a.bias = w.bias;
@@ -1319,11 +1344,13 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
 // AdaIN (ops.py:282-294): out = alpha*((x-mu_c)*rsqrt(var_c+eps)*sqrt(var_s)+mu_s) + (1-alpha)*x
 // ---------------------------------------------------------------------------
 __global__ void adain_apply_kernel(const float* x, size_t n4_per_pair, int C, const float* mean, const float* var,
-                                   float alpha, float eps, half_t* out16, float* out32) {
+                                   float alpha, float eps, half_t* out16, float* out32, int shared_style) {
   const int pair = blockIdx.y;
   const int cq = C / 4;
   const float* mp = mean + (size_t)pair * 2 * C;
   const float* vp = var + (size_t)pair * 2 * C;
+  const float* ms = mean + (size_t)(shared_style ? 0 : pair) * 2 * C + C;   // style moments
+  const float* vs = var + (size_t)(shared_style ? 0 : pair) * 2 * C + C;
   const size_t base = (size_t)pair * n4_per_pair;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4_per_pair; i += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % cq) * 4;
@@ -1332,7 +1359,7 @@ __global__ void adain_apply_kernel(const float* x, size_t n4_per_pair, int C, co
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float inv = 1.f / sqrtf(vp[c + j] + eps);
-      const float y = (v[j] - mp[c + j]) * inv * sqrtf(vp[C + c + j]) + mp[C + c + j];
+      const float y = (v[j] - mp[c + j]) * inv * sqrtf(vs[c + j]) + ms[c + j];
       o[j] = alpha * y + (1.f - alpha) * v[j];
     }
     if (out32) *reinterpret_cast<f32x4*>(out32 + (base + i) * 4) = o;
@@ -1346,16 +1373,16 @@ __global__ void adain_apply_kernel(const float* x, size_t n4_per_pair, int C, co
 }
 
 int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, float eps,
-                 half_t* out16, float* out32, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                 half_t* out16, float* out32, void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style) {
   ARG_CHECK(C % 4 == 0 && C <= 1024 && Nc >= 1 && Ns >= 1 && P >= 1 && P <= 32);
   WctCarve w = carve(workspace, C < 32 ? 32 : C, Nc, Ns, P);
   ARG_CHECK(workspace_bytes >= w.total);
   int rc;
-  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, true, s))) return rc;
+  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, true, shared_style, s))) return rc;
   const size_t n4 = (size_t)Nc * C / 4;
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adain_apply_kernel, dim3((unsigned)blocks, P), dim3(256), 0, s, content, n4, C, w.mean, w.var, alpha, eps, out16, out32);
+  hipLaunchKernelGGL(adain_apply_kernel, dim3((unsigned)blocks, P), dim3(256), 0, s, content, n4, C, w.mean, w.var, alpha, eps, out16, out32, shared_style);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
@@ -1526,7 +1553,7 @@ int launch_style_swap(const float* content, int hc, int wc, const float* style, 
   int rc;
   // statistics, covariances (+eps I), eigendecompositions: the same stages as wct_tf
   if ((rc = launch_wct(content, Nc, style, Ns, C, 1, alpha, WCT_MODE_TF, eps, nullptr, nullptr, workspace, wct_bytes,
-                       nullptr, WCT_STAGE_COV | WCT_STAGE_EIG, s, nullptr, 0, nullptr, nullptr))) return rc;
+                       nullptr, WCT_STAGE_COV | WCT_STAGE_EIG, s, nullptr, 0, nullptr, nullptr, 0))) return rc;
   const size_t cc = (size_t)C * C;
   float *d_cw = sw.d3, *d_sw = sw.d3 + C, *d_sc = sw.d3 + 2 * C;
   hipLaunchKernelGGL(swap_gain_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, w.A, d_cw, d_sw, d_sc, C);

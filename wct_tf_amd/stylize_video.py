@@ -1,0 +1,178 @@
+"""`python -m wct_tf_amd.stylize_video ...`: the reference's stylize_video.py (stylize_video.py:16-160) on the
+MI355X path.  Same flags.  Differences, all forced by the environment or by the hardware:
+
+* `--in-path` may be a DIRECTORY of frames (ffmpeg is not in this image).  A video file works
+  when an `ffmpeg` binary is on PATH: frames are extracted to `--tmp-dir` and the stylized frames are
+  re-encoded, exactly as the reference does (stylize_video.py:73-80,136-150).  Without ffmpeg the stylized
+  frames are left in `<out-path>/<video>_<style>/`.
+* The reference calls `predict()` once per frame, which re-runs the style encoder, the style statistics and
+  the style eigendecompositions for every frame (stylize_video.py:112-121).  Here the frames of a video go
+  through `WCT.predict_frames` in batches that share ONE style: the style side runs once per batch
+  (WCT_FLAG_STYLE_SHARED) and every frame is bit-identical to `predict(frame, style)`.  With
+  `--keep-colors` the style image is CORAL-matched to every frame (stylize_video.py:116-119) and therefore
+  differs per frame: those frames go through the per-pair batch instead.
+"""
+from __future__ import division, print_function
+
+import argparse
+import os
+import random
+import re
+import shutil
+import subprocess
+import time
+
+import numpy as np
+
+from .utils import get_files, get_img, save_img, resize_to, center_crop, _imresize
+from .wct import WCT
+
+TMP_DIR = '_____fns_frames_%s/' % random.randint(0, 99999)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--checkpoints', nargs='+', type=str, help='List of decoder weight files/dirs', default=None)
+    parser.add_argument('--relu-targets', nargs='+', type=str, help='List of reluX_1 layers, corresponding to --checkpoints', required=True)
+    parser.add_argument('--vgg-path', type=str, help='Path to the encoder weights', default=None)
+    parser.add_argument('--in-path', type=str, help='Path to a video file (needs ffmpeg) or a directory of frames', required=True)
+    parser.add_argument('--out-path', type=str, help='Output folder path', required=True)
+    parser.add_argument('--style-path', type=str, help='Path to style image (or a folder of them)', required=True)
+    parser.add_argument('--tmp-dir', type=str, dest='tmp_dir', help='tmp dir for processing', default=TMP_DIR)
+    parser.add_argument('--keep-tmp', action='store_true', help='Don\'t remove stylized image tmp dir after', default=False)
+    parser.add_argument('--keep-colors', action='store_true', help="Preserve the colors of the style image", default=False)
+    parser.add_argument('--style-size', type=int, help="Resize style image to this size before cropping", default=0)
+    parser.add_argument('--crop-size', type=int, help="Crop square size", default=0)
+    parser.add_argument('--content-size', type=int, help="Resize short side of content image to this", default=0)
+    parser.add_argument('--passes', type=int, help="# of stylization passes per content image", default=1)
+    parser.add_argument('--device', type=str, help='Device to perform compute on, e.g. /gpu:0', default='/gpu:0')
+    parser.add_argument('--alpha', type=float, help="Alpha blend value", default=1)
+    parser.add_argument('--concat', action='store_true', help="Concatenate style image and stylized output", default=False)
+    # Style swap args
+    parser.add_argument('--swap5', action='store_true', help="Swap style on layer relu5_1", default=False)
+    parser.add_argument('--ss-alpha', type=float, help="Style swap alpha blend", default=0.6)
+    parser.add_argument('--ss-patch-size', type=int, help="Style swap patch size", default=3)
+    parser.add_argument('--ss-stride', type=int, help="Style swap stride", default=1)
+    # additions of this path
+    parser.add_argument('--adain', action='store_true', help="Use AdaIN instead of WCT", default=False)
+    parser.add_argument('--batch', type=int, default=16, help='frames per device batch (<= 32)')
+    parser.add_argument('--fps', type=int, default=30, help='frame rate of the re-encoded video (reference: 30)')
+    parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED',
+                        help='use seeded synthetic weights instead of --checkpoints/--vgg-path')
+    parser.add_argument('--wct-mode', choices=['tf', 'np'], default='tf', help='wct_tf (graph) or wct_np semantics')
+    return parser
+
+
+def natural_key(path):
+    """frame_2.png before frame_10.png (ffmpeg's %d numbering, stylize_video.py:76)."""
+    return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', os.path.basename(path))]
+
+
+def list_frames(in_dir):
+    return sorted(get_files(in_dir), key=natural_key)
+
+
+def stylize_frames(wct_model, frame_files, style_img, args):
+    """Yield (frame_file, stylized uint8 image) in order; consecutive same-sized frames are batched."""
+    def load(f):
+        img = get_img(f)
+        if args.content_size > 0:
+            img = resize_to(img, args.content_size)
+        return img
+
+    def run(frames, style):
+        out = wct_model.predict_frames(frames, style, args.alpha, args.swap5, args.ss_alpha, args.adain, batch=args.batch)
+        for _ in range(args.passes - 1):                      # later passes: plain WCT, as stylize_video.py:124-126
+            out = wct_model.predict_frames(out, style, args.alpha, adain=args.adain, batch=args.batch)
+        return out
+
+    i = 0
+    while i < len(frame_files):
+        first = load(frame_files[i])
+        group_files, group = [frame_files[i]], [first]
+        i += 1
+        while i < len(frame_files) and len(group) < args.batch:
+            nxt = load(frame_files[i])
+            if nxt.shape != first.shape:
+                break
+            group_files.append(frame_files[i])
+            group.append(nxt)
+            i += 1
+        frames = np.stack(group)
+        if args.keep_colors:
+            # the style differs per frame (CORAL towards each frame): per-pair batch
+            from .ops import preserve_colors_np
+            styles = np.stack([preserve_colors_np(style_img, f, ctx=wct_model.sess) for f in group])
+            outs = wct_model.sess.stylize_batch(frames, styles, wct_model.relu_targets, alpha=args.alpha,
+                                                adain=args.adain, wct_mode=wct_model.wct_mode)
+            for _ in range(args.passes - 1):
+                outs = wct_model.sess.stylize_batch(outs, styles, wct_model.relu_targets, alpha=args.alpha,
+                                                    adain=args.adain, wct_mode=wct_model.wct_mode)
+            style_per_frame = list(styles)
+        else:
+            outs = run(frames, style_img)
+            style_per_frame = [style_img] * len(group)
+        for f, o, s in zip(group_files, outs, style_per_frame):
+            if args.concat:                                   # stylize_video.py:129-132
+                o = np.hstack([_imresize(s, (o.shape[0], o.shape[0])), o])
+            yield f, o
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    start = time.time()
+    weights = None
+    if args.synthetic_weights is not None:
+        from .weights import synthetic_weights
+        weights = synthetic_weights(args.synthetic_weights, relu_targets=args.relu_targets)
+    wct_model = WCT(checkpoints=args.checkpoints, relu_targets=args.relu_targets, vgg_path=args.vgg_path,
+                    device=args.device, ss_patch_size=args.ss_patch_size, ss_stride=args.ss_stride,
+                    weights=weights, wct_mode=args.wct_mode)
+    if args.keep_colors and args.swap5:
+        raise SystemExit('--keep-colors with --swap5 is not batched here: use stylize.py per frame')
+
+    ffmpeg = shutil.which('ffmpeg')
+    is_video = not os.path.isdir(args.in_path)
+    if is_video and ffmpeg is None:
+        raise SystemExit('--in-path is a file and there is no ffmpeg on PATH: pass a directory of frames')
+    in_dir = args.in_path
+    if is_video:
+        in_dir = os.path.join(args.tmp_dir, 'input')
+        os.makedirs(in_dir, exist_ok=True)
+        subprocess.check_call([ffmpeg, '-i', args.in_path, '%s/frame_%%d.png' % in_dir])
+    frame_files = list_frames(in_dir)
+    style_files = get_files(args.style_path) if os.path.isdir(args.style_path) else [args.style_path]
+    os.makedirs(args.out_path, exist_ok=True)
+
+    content_prefix, content_ext = os.path.splitext(os.path.basename(os.path.normpath(args.in_path)))
+    count = 0
+    for style_fullpath in style_files:
+        style_img = get_img(style_fullpath)
+        if args.style_size > 0:
+            style_img = resize_to(style_img, args.style_size)
+        if args.crop_size > 0:
+            style_img = center_crop(style_img, args.crop_size)
+        style_prefix = os.path.splitext(os.path.basename(style_fullpath))[0]
+        out_dir = os.path.join(args.tmp_dir, 'sytlized') if is_video else \
+            os.path.join(args.out_path, '{}_{}'.format(content_prefix, style_prefix))
+        os.makedirs(out_dir, exist_ok=True)
+        for f, stylized in stylize_frames(wct_model, frame_files, style_img, args):
+            out_f = os.path.join(out_dir, os.path.basename(f))
+            save_img(out_f, stylized)
+            count += 1
+        if is_video:
+            out_v = os.path.join(args.out_path, '{}_{}{}'.format(content_prefix, style_prefix, content_ext))
+            subprocess.check_call([ffmpeg, '-i', '%s/frame_%%d.png' % out_dir, '-f', 'mp4', '-q:v', '0', '-vcodec', 'mpeg4',
+                                   '-r', str(args.fps), '-y', out_v])
+            print('Video at: %s' % out_v)
+            if not args.keep_tmp:
+                shutil.rmtree(out_dir)
+    if is_video and not args.keep_tmp:
+        shutil.rmtree(args.tmp_dir, ignore_errors=True)
+    dt = time.time() - start
+    print('Finished stylizing {} frames in {:.1f}s ({:.1f} frames/s incl. image I/O)'.format(count, dt, count / max(dt, 1e-9)))
+    return count
+
+
+if __name__ == '__main__':
+    main()

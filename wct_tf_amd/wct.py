@@ -99,3 +99,28 @@ class WCT(object):
             style = np.uint8(np.clip(style, 0, 255))
         return self.sess.stylize(content, style, self.relu_targets, alpha=alpha, adain=adain,
                                  wct_mode=self.wct_mode, swap5=bool(swap5))
+
+    def predict_frames(self, frames, style, alpha=1, swap5=False, ss_alpha=1, adain=False, batch=16):
+        '''Stylize same-sized frames [F][H][W][3] with ONE style image (the loop of stylize_video.py:112-121,
+           which calls predict() once per frame and so re-runs the style encoder, the style statistics and the
+           style eigendecompositions every frame).  Here the style side runs once per batch of `batch` frames;
+           every frame equals predict(frame, style) bit for bit.  Returns uint8 [F][Ho][Wo][3].'''
+        frames = np.asarray(frames)
+        style = np.asarray(style)
+        assert frames.ndim == 4 and style.ndim == 3
+        if frames.dtype != np.uint8:
+            frames = np.uint8(np.clip(frames, 0, 255))
+        if style.dtype != np.uint8:
+            style = np.uint8(np.clip(style, 0, 255))
+        if swap5 is True and self.ss_stride != 1:
+            from .utils import swap_filter_fit, center_crop_to
+            should_refit, H, W = swap_filter_fit(frames.shape[1], frames.shape[2], self.ss_patch_size, self.ss_stride)
+            if should_refit:
+                frames = np.stack([center_crop_to(f, H, W) for f in frames])
+        if swap5:
+            self.sess.set_style_swap(ss_alpha, self.ss_patch_size, self.ss_stride)
+        batch = max(1, min(32, int(batch)))
+        outs = [self.sess.stylize_batch(frames[i:i + batch], style, self.relu_targets, alpha=alpha, adain=adain,
+                                        wct_mode=self.wct_mode, swap5=bool(swap5))
+                for i in range(0, len(frames), batch)]
+        return np.concatenate(outs, axis=0)
