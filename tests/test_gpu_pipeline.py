@@ -353,3 +353,37 @@ def test_video_cli_end_to_end(tmp_path):
         want = model.predict(f, style, 0.8)
         want = np.hstack([utils._imresize(style, (want.shape[0], want.shape[0])), want])
         assert np.array_equal(got, want), i
+
+
+def test_wct_facade_from_tf_checkpoint_dirs(tmp_path, weights):
+    """WCT(checkpoints=[dir, ...]) with TensorFlow V2 bundles (the reference's own decoder format, wct.py:46-58):
+    same frames as with the weights handed over directly."""
+    from oracle.tf_ckpt_writer import write_bundle, write_checkpoint_state
+    from wct_tf_amd.weights import decoder_plan, save_weights
+    from wct_tf_amd.wct import WCT
+    targets = ['relu2_1', 'relu1_1']
+    dirs = []
+    for relu in targets:
+        t, count, convs = {}, 0, iter(weights['decoder'][relu])
+        for kind, cin, cout, _ in decoder_plan(relu):
+            if kind == 'U':
+                count += 1
+                continue
+            w, b = next(convs)
+            base = 'encoder_decoder_{r}/decoder_{r}/decoder_model_{r}/{r}_{c}/'.format(r=relu, c=count)
+            t[base + 'kernel'], t[base + 'bias'] = np.float32(w), np.float32(b)
+            t[base + 'kernel/Adam'] = np.zeros_like(np.float32(w))
+            count += 1
+        d = tmp_path / ('ckpt_' + relu)
+        d.mkdir()
+        write_bundle(str(d / 'model.ckpt-15000'), t, block_size=512)
+        write_checkpoint_state(str(d), 'model.ckpt-15000')
+        dirs.append(str(d))
+    vgg = str(tmp_path / 'vgg.npz')
+    save_weights(vgg, {'encoder': weights['encoder'], 'decoder': {}})
+    content, style = synthetic_image(700, 40, 48), synthetic_image(701, 32, 32)
+    a = WCT(checkpoints=dirs, relu_targets=targets, vgg_path=vgg).predict(content, style, 0.6)
+    b = WCT(checkpoints=None, relu_targets=targets, vgg_path=None, weights=weights).predict(content, style, 0.6)
+    assert np.array_equal(a, b)
+    with pytest.raises(Exception, match='No checkpoint found for target relu1_1'):
+        WCT(checkpoints=[dirs[0], str(tmp_path)], relu_targets=targets, vgg_path=vgg)

@@ -4,9 +4,11 @@
     WCT.predict(content, style, alpha=1, swap5=False, ss_alpha=1, adain=False) -> uint8 HxWx3
 
 `checkpoints` / `vgg_path`: the reference restores TF checkpoints and a .t7 file
-(wct.py:46-58, vgg_normalised.py:16).  Neither format's weights exist offline, so
-this class takes, per decoder, a path to a .npz written by
-`wct_tf_amd.weights.save_weights` (or a weights dict via `weights=`); a missing
+(wct.py:46-58, vgg_normalised.py:16).  Per decoder this class takes either of
+  * a TF checkpoint directory (a `checkpoint` state file + V2 bundle, read by
+    wct_tf_amd/tf_ckpt.py without TensorFlow) -- the reference's own format,
+  * a .npz written by `wct_tf_amd.weights.save_weights` (file, or `decoder_<relu>.npz` in a directory),
+or a weights dict via `weights=`; `vgg_path` is the reference's `.t7` or a .npz.  A missing
 decoder raises like the reference does (wct.py:58).
 """
 import os
@@ -53,6 +55,10 @@ class WCT(object):
                     weights['encoder'] = load_weights(vgg_path)['encoder']
             for relu_target, checkpoint_dir in zip(relu_targets, checkpoints or []):
                 path = checkpoint_dir
+                if os.path.isdir(path) and os.path.exists(os.path.join(path, 'checkpoint')):
+                    from .tf_ckpt import decoder_weights_from_checkpoint     # tf.train.Saver layout (wct.py:46-58)
+                    weights['decoder'][relu_target] = decoder_weights_from_checkpoint(path, relu_target)
+                    continue
                 if os.path.isdir(path):
                     path = os.path.join(path, 'decoder_{}.npz'.format(relu_target))
                 if not os.path.exists(path):
