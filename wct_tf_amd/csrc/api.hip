@@ -55,7 +55,7 @@ struct wct_ctx {
   int nside = 3;
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   bool enc_loaded = false;
-  float* first_w = nullptr;        // folded conv1_1 [27][64]
+  half_t* first_w = nullptr;       // folded conv1_1 as fp16 hi/lo MFMA fragments (ConvFirstArgs::wfrag)
   float* first_b = nullptr;
   ConvLayer enc[12];               // conv1_2 .. conv5_1
   Decoder dec[6];
@@ -301,7 +301,20 @@ extern "C" int wct_set_encoder(wct_ctx* c, const float* pre_w, const float* pre_
       }
   if (c->first_w) { hipFree(c->first_w); c->first_w = nullptr; }
   if (c->first_b) { hipFree(c->first_b); c->first_b = nullptr; }
-  TRY(upload(c, fw.data(), fw.size() * sizeof(float), (void**)&c->first_w));
+  // hi/lo split fragments: lane l of fragment (t, ks) holds channel 32t + (l&31), k = 16ks + 8(l>>5) .. +7
+  std::vector<half_t> frag(2 * 2 * 2 * 64 * 8);
+  for (int t = 0; t < 2; ++t)
+    for (int ks = 0; ks < 2; ++ks)
+      for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+          const int co = t * 32 + (l & 31), k = ks * 16 + (l >> 5) * 8 + j;
+          const float wv = k < 27 ? fw[k * 64 + co] : 0.f;
+          const half_t hi = (half_t)wv;
+          const half_t lo = (half_t)(wv - (float)hi);
+          frag[((((t * 2 + ks) * 2 + 0) * 64) + l) * 8 + j] = hi;
+          frag[((((t * 2 + ks) * 2 + 1) * 64) + l) * 8 + j] = lo;
+        }
+  TRY(upload(c, frag.data(), frag.size() * sizeof(half_t), (void**)&c->first_w));
   TRY(upload(c, fb.data(), fb.size() * sizeof(float), (void**)&c->first_b));
   for (int i = 0; i < 12; ++i) TRY(pack_conv(c, w[i + 1], b[i + 1], ENC_CIN[i], ENC_COUT[i], &c->enc[i]));
   c->enc_loaded = true;
@@ -393,7 +406,7 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
   half_t* nxt = (half_t*)c->act[1].p;
   {
     ConvFirstArgs a;
-    a.x = img; a.w = c->first_w; a.bias = c->first_b;
+    a.x = img; a.wfrag = c->first_w; a.bias = c->first_b;
     a.y16 = deepest > 1 ? cur : nullptr; a.y32 = taps32[1];
     a.B = B; a.H = H; a.W = W; a.clamp01 = clamp01;
     const double px = (double)B * H * W;

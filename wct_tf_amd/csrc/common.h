@@ -55,7 +55,7 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 
 struct ConvFirstArgs {   // 3 -> 64 with the 1x1 'preprocess' folded in
   const float* x;      // [B][H][W][3] fp32 image in [0,1]
-  const float* w;      // [27][64] folded weights (tap*3+cin major)
+  const half_t* wfrag; // folded weights as fp16 hi/lo MFMA A-fragments [cout/32][k-step 2][hi,lo][lane][8], k = tap*3+cin (27 -> 32)
   const float* bias;   // [64]
   half_t* y16;
   float* y32;

@@ -323,76 +323,131 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// conv1_1: 3 -> 64, fp32 image in, VALU direct conv (K = 27 is too thin for MFMA;
-// the layer is bound by its 64-channel output write)
+// conv1_1: 3 -> 64 with the folded preprocess, fp32 image in.  The layer is all output: 64 channels
+// written per 3 read.  K = 27 (padded to 32) runs on the MFMA pipe at fp32-product accuracy: image
+// values and weights are split into fp16 hi + lo pairs (22 significand bits), hi*hi + hi*lo + lo*hi
+// accumulate in fp32 (three v_mfma_f32_32x32x16_f16 per k-step; the VALU version spent 1728 FMAs per
+// thread and was VALU-bound at 1.4 TB/s).  The MFMA layout leaves a lane with 4 channels of one
+// pixel, which would store 32 B per pixel and instruction; the results therefore go through a
+// per-wave LDS transpose and leave as whole pixel rows (256 B fp32 / 128 B fp16): every store
+// instruction writes 1 KiB of contiguous memory.
+// k = ky*9 + kx*3 + c: a patch row [px][3] holds the 9 values of a ky contiguously.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int tiles_x) {
-  // 16x16 pixel tile x 64 channels per block.  Thread t owns channel chunk (t & 7) (8 channels)
-  // of the 8 pixels (t >> 3) + 32 i: the 8 lanes of a pixel write its 128 B (fp16) contiguously,
-  // so one store instruction covers 8 whole pixels.
-  __shared__ float patch[18 * 18 * 3];
-  __shared__ __attribute__((aligned(16))) float wl[27 * 64];
-  const int tid = threadIdx.x;
+  // 16x16 pixel tile x 64 channels per block; wave w owns pixel rows 4w..4w+3 (two 2x16 MFMA pixel tiles)
+  __shared__ float patch[18 * 18 * 3 + 4];     // [972] stays 0: the target of the padded k = 27..31
+  __shared__ __attribute__((aligned(16))) unsigned char tr[4][32 * 256];   // per wave: 32 pixels x 64 ch fp32
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int b = blockIdx.y;
   const int y0 = ty * 16, x0 = tx * 16;
   const float* xb = p.x + (size_t)b * p.H * p.W * 3;
-  for (int i = tid; i < 18 * 18 * 3; i += 256) {
-    int c = i % 3, pix = i / 3;
-    int py = pix / 18, px = pix - py * 18;
-    int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
-    float v = xb[((size_t)iy * p.W + ix) * 3 + c];
-    if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+  for (int i = tid; i < 18 * 18 * 3 + 4; i += 256) {
+    float v = 0.f;
+    if (i < 18 * 18 * 3) {
+      int c = i % 3, pix = i / 3;
+      int py = pix / 18, px = pix - py * 18;
+      int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
+      v = xb[((size_t)iy * p.W + ix) * 3 + c];
+      if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    }
     patch[i] = v;
   }
-  for (int i = tid; i < 27 * 64 / 4; i += 256)
-    reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+  // weight fragments [cout tile][k-step][hi/lo][lane][8]: 8 coalesced 1-KiB loads, register-resident
+  half8 wh[2][2], wl[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      wh[t][ks] = *reinterpret_cast<const half8*>(p.wfrag + (((t * 2 + ks) * 2 + 0) * 64 + lane) * 8);
+      wl[t][ks] = *reinterpret_cast<const half8*>(p.wfrag + (((t * 2 + ks) * 2 + 1) * 64 + lane) * 8);
+    }
+  const int frag_px = lane & 15, frag_py = (lane & 31) >> 4, kgrp = lane >> 5;
+  // byte address of patch element k of this lane's pixel in tile row pair 0 of the wave (mt adds an immediate)
+  int addr[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = ks * 16 + kgrp * 8 + j;
+      const int ky = k / 9, kp = k - ky * 9;
+      addr[ks][j] = k < 27 ? (((wave * 4 + frag_py + ky) * 18 + frag_px) * 3 + kp) * 4 : 972 * 4;
+    }
+  f32x4 bias[2][4];                            // bias of this lane's channels (nt, rq)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) bias[nt][rq] = *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + 8 * rq + 4 * kgrp);
   __syncthreads();
-  const int chunk = tid & 7, pg = tid >> 3;
-  float acc[8][8];
-  {
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + chunk * 8);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + chunk * 8 + 4);
+  const unsigned char* pb = reinterpret_cast<const unsigned char*>(patch);
+  unsigned char* const wt = tr[wave];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+  for (int mt = 0; mt < 2; ++mt) {
+    f32x16 acc[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[i][j] = b0[j]; acc[i][4 + j] = b1[j]; }
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 bh, bl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // the padded-k slot must not move with mt: its address is absolute
+        const int off = (ks * 16 + kgrp * 8 + j < 27) ? mt * 2 * 54 * 4 : 0;
+        const float v = *reinterpret_cast<const float*>(pb + addr[ks][j] + off);
+        bh[j] = (half_t)v;
+        bl[j] = (half_t)(v - (float)bh[j]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[nt][ks], bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[nt][ks], bl, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[nt][ks], bh, acc[nt], 0, 0, 0);
+      }
     }
-  }
-#pragma unroll 3
-  for (int k = 0; k < 27; ++k) {
-    const int tap = k / 3, c = k - tap * 3;
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + k * 64 + chunk * 8);
-    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + k * 64 + chunk * 8 + 4);
+    // transpose through LDS: pixel row = 64 fp32 = 16 pieces of 16 B, piece index XOR (pixel & 15)
+    const int px = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int pix = pg + 32 * i;
-      const float in = patch[(((pix >> 4) + ky) * 18 + (pix & 15) + kx) * 3 + c];
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[i][j] = fmaf(in, w0[j], acc[i][j]); acc[i][4 + j] = fmaf(in, w1[j], acc[i][4 + j]); }
-    }
-  }
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 v;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int pix = pg + 32 * i;
-    const int oy = y0 + (pix >> 4), ox = x0 + (pix & 15);
-    if (oy >= p.H || ox >= p.W) continue;
-    const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * 64 + chunk * 8;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[i][j], 0.f);
-    if (p.y16) {
-      half8 h;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) h[j] = (half_t)v[j];
-      *reinterpret_cast<half8*>(p.y16 + o) = h;
-    }
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[nt][rq * 4 + j] + bias[nt][rq][j], 0.f);
+        const int piece = nt * 8 + 2 * rq + kgrp;
+        *reinterpret_cast<f32x4*>(wt + (px * 16 + (piece ^ (px & 15))) * 16) = v;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int oy0 = y0 + wave * 4 + mt * 2;
     if (p.y32) {
-      f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
-      *reinterpret_cast<f32x4*>(p.y32 + o) = v0;
-      *reinterpret_cast<f32x4*>(p.y32 + o + 4) = v1;
+      const int piece = lane & 15;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int q = it * 4 + (lane >> 4);
+        const int oy = oy0 + (q >> 4), ox = x0 + (q & 15);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wt + (q * 16 + (piece ^ (q & 15))) * 16);
+        if (oy < p.H && ox < p.W) *reinterpret_cast<f32x4*>(p.y32 + (((size_t)b * p.H + oy) * p.W + ox) * 64 + piece * 4) = v;
+      }
     }
+    if (p.y16) {
+      const int c8 = lane & 7;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int q = it * 8 + (lane >> 3);
+        const int oy = oy0 + (q >> 4), ox = x0 + (q & 15);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(wt + (q * 16 + ((2 * c8) ^ (q & 15))) * 16);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(wt + (q * 16 + ((2 * c8 + 1) ^ (q & 15))) * 16);
+        half8 h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = (half_t)v0[j]; h[4 + j] = (half_t)v1[j]; }
+        if (oy < p.H && ox < p.W) *reinterpret_cast<half8*>(p.y16 + (((size_t)b * p.H + oy) * p.W + ox) * 64 + c8 * 8) = h;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();           // the region is rewritten by the next pixel tile
   }
 }
 
