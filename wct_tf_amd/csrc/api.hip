@@ -42,7 +42,7 @@ struct Decoder {
   bool loaded = false;
   std::vector<PlanStep> plan;
   std::vector<ConvLayer> convs;    // every conv but the last
-  half_t* last_w = nullptr;        // [9][32][3][2] fp16 pairs (see ConvLastArgs)
+  half_t* last_w = nullptr;        // MFMA A-fragments of the 64->3 conv (see ConvLastArgs::wfrag)
   float* last_b = nullptr;
 };
 
@@ -356,11 +356,16 @@ extern "C" int wct_set_decoder(wct_ctx* c, int level, const float* const* w, con
   for (auto& s : d.plan) {
     if (s.kind != 'C') continue;
     if (s.cout == 3) {
-      // HWIO [3][3][64][3] = [(tap*64+cin)][3] -> [(tap*32+cin/2)][3][2] fp16 pairs
-      std::vector<half_t> w16((size_t)576 * 3);
-      for (int t = 0; t < 9 * 32; ++t)
-        for (int o = 0; o < 3; ++o)
-          for (int h = 0; h < 2; ++h) w16[((size_t)t * 3 + o) * 2 + h] = (half_t)w[i][((size_t)t * 2 + h) * 3 + o];
+      // HWIO [3][3][64][3] = [(tap*64+cin)][3] -> A fragments of the 32 x 64 matrix with row tap*3+cout:
+      // lane l of k-step ks holds row l&31, cin = 16 ks + 8 (l>>5) .. +7
+      std::vector<half_t> w16((size_t)4 * 64 * 8);
+      for (int ks = 0; ks < 4; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) {
+            const int row = l & 31, cin = ks * 16 + (l >> 5) * 8 + j;
+            const int tap = row / 3, co = row % 3;
+            w16[((size_t)ks * 64 + l) * 8 + j] = row < 27 ? (half_t)w[i][((size_t)tap * 64 + cin) * 3 + co] : (half_t)0.f;
+          }
       TRY(upload(c, w16.data(), w16.size() * sizeof(half_t), (void**)&d.last_w));
       TRY(upload(c, b[i], 3 * sizeof(float), (void**)&d.last_b));
     } else {
@@ -458,7 +463,7 @@ static int run_decoder(wct_ctx* c, int level, const half_t* feat16, int B, int h
     if (s.cout == 3) {
       ARG_CHECK(up == 0);
       ConvLastArgs a;
-      a.x = cur; a.w16 = d.last_w; a.bias = d.last_b; a.y = img_out; a.B = B; a.H = h; a.W = w;
+      a.x = cur; a.wfrag = d.last_w; a.bias = d.last_b; a.y = img_out; a.B = B; a.H = h; a.W = w;
       const double px = (double)B * h * w;
       ProfScope ps(c, 2, 2.0 * px * 576 * 3, px * (128 + 12));
       TRY(launch_conv_last(a, c->stream));

@@ -66,7 +66,7 @@ int launch_conv_first(const ConvFirstArgs& a, hipStream_t s);
 
 struct ConvLastArgs {    // 64 -> 3, no activation (model.py:298)
   const half_t* x;     // [B][H][W][64]
-  const half_t* w16;   // [9][32][3][2] fp16: (cin, cin+1) pairs per output, for v_dot2_f32_f16
+  const half_t* wfrag; // fp16 MFMA A-fragments [k-step 4][lane][8]: row tap*3+cout (27 of 32), k = cin
   const float* bias;   // [3]
   float* y;            // [B][H][W][3] fp32, unclipped
   int B, H, W;

@@ -460,46 +460,53 @@ int launch_conv_first(const ConvFirstArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// decoder output conv: 64 -> 3, no activation, fp32 out (bound by the 64-ch read)
+// decoder output conv: 64 -> 3, no activation, fp32 out.  Three output channels would waste the MFMA
+// tile, so the taps are moved to the output side: stage 1 computes, for every pixel q of the 18x18
+// halo patch, the 27 partial products  P[tap*3+co][q] = sum_c W[tap][c][co] x[q][c]  -- a 32 x 64 x 324
+// GEMM on v_mfma_f32_32x32x16_f16 (27 of 32 rows used) whose pixel fragments come straight from global
+// memory (each activation is read once, no LDS patch); stage 2 adds the 9 shifted partials per output
+// pixel out of LDS (27 floats per pixel instead of 72 16-B patch reads and 864 dot products).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_last_kernel(ConvLastArgs p, int tiles_x) {
-  // patch [18][18] pixels x 64 ch fp16 = 128 B per pixel, 16-B pieces XOR-swizzled
-  __shared__ __attribute__((aligned(16))) unsigned char patch[18 * 18 * 128];
-  const int tid = threadIdx.x;
+  constexpr int PP = 33;                                   // partials pitch per patch pixel (odd: conflict-free)
+  __shared__ float part[18 * 18 * PP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int b = blockIdx.y;
   const int y0 = ty * 16, x0 = tx * 16;
   const half_t* xb = p.x + (size_t)b * p.H * p.W * 64;
-  for (int item = tid; item < 18 * 18 * 8; item += 256) {
-    int pix = item >> 3, chunk = item & 7;
-    int py = pix / 18, px = pix - py * 18;
-    int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
-    uint4 v = *reinterpret_cast<const uint4*>(xb + ((size_t)iy * p.W + ix) * 64 + chunk * 8);
-    *reinterpret_cast<uint4*>(patch + (pix * 8 + (chunk ^ ((px >> 1) & 7))) * 16) = v;
+  half8 wf[4];                                             // A fragments: rows tap*3+co, k = 16 ks + 8 (lane>>5) ..
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const half8*>(p.wfrag + (ks * 64 + lane) * 8);
+  for (int tile = wave; tile < 11; tile += 4) {            // 324 patch pixels = 11 tiles of 32 (the last one partial)
+    const int q = tile * 32 + (lane & 31);
+    const int qq = q < 324 ? q : 323;
+    const int py = qq / 18, px = qq - py * 18;
+    const int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
+    const half_t* src = xb + ((size_t)iy * p.W + ix) * 64 + (lane >> 5) * 8;
+    half8 bf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const half8*>(src + ks * 16);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bf[ks], acc, 0, 0, 0);
+    if (q < 324) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)                         // register r = row (r&3) + 8 (r>>2) + 4 (lane>>5)
+        part[q * PP + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = acc[r];
+    }
   }
   __syncthreads();
   const int ly = tid >> 4, lx = tid & 15;
   const int oy = y0 + ly, ox = x0 + lx;
   float a0 = p.bias[0], a1 = p.bias[1], a2 = p.bias[2];
-  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-  const half2_t* w2 = reinterpret_cast<const half2_t*>(p.w16);     // [tap][cin/2][3] pairs of fp16 weights
-#pragma unroll 1
+#pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
-    const int py = ly + ky, px = lx + kx;
-    const int pix = py * 18 + px;
-#pragma unroll
-    for (int chunk = 0; chunk < 8; ++chunk) {
-      half8 h = *reinterpret_cast<const half8*>(patch + (pix * 8 + (chunk ^ ((px >> 1) & 7))) * 16);
-      const half2_t* wk = w2 + (tap * 32 + chunk * 4) * 3;          // uniform address -> scalar loads
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        half2_t xv = {h[2 * j], h[2 * j + 1]};
-        a0 = __builtin_amdgcn_fdot2(xv, wk[j * 3 + 0], a0, false);  // v_dot2_f32_f16: 2 MACs, fp32 accumulate
-        a1 = __builtin_amdgcn_fdot2(xv, wk[j * 3 + 1], a1, false);
-        a2 = __builtin_amdgcn_fdot2(xv, wk[j * 3 + 2], a2, false);
-      }
-    }
+    const float* pq = part + ((ly + ky) * 18 + lx + kx) * PP + tap * 3;
+    a0 += pq[0]; a1 += pq[1]; a2 += pq[2];
   }
   if (oy < p.H && ox < p.W) {
     float* o = p.y + (((size_t)b * p.H + oy) * p.W + ox) * 3;
