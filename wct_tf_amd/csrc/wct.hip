@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <map>
 #include <string>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------
 // K3: per-channel sums over the pixel axis
@@ -511,8 +512,9 @@ __device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq,
   const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
   // (a) both diagonals far below the 1e-5 cut-off: whatever they mix stays dropped;
   // (b) coupling of a kept direction into a noise-level one with a negligible angle
-  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) && !(small < JACOBI_FLOOR && aapq < 1e-6f * big);
-  const bool rot = live && (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) && (aapq > 1e-36f);
+  // bitwise & / | on the predicates: && would become an exec-mask branch around the second half
+  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
+  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
   const float rel = den2 > 0.f ? fminf(aapq * __builtin_amdgcn_rsqf(den2), 1.f) : 1.f;
   const float tau = 0.5f * (aqq - app);
   const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
@@ -613,6 +615,78 @@ __device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& m
   return cur;
 }
 
+
+// The cross sweep (one outer step: N/2 rotation sets over the (N/2)^2 pairs (i in I, j in J)), written for
+// instruction count: it is issue-bound (16 waves per block, two blocks per CU).  Relative to the generic
+// jacobi_sets: p indices are fixed per thread and q indices advance by one per set, so the byte offsets are
+// carried incrementally; the loop is unrolled over the two ping-pong images so that the image, D and O
+// selectors are immediates of the LDS instructions; the owner-only D/O updates are unconditional stores to
+// the real slot or to a dummy slot (no exec-mask branches); the rotation is branch-free; scalar FMAs only
+// (hipcc's packed-f32 form of the same arithmetic spent 9 v_mov per set on operand assembly).
+// 149 -> ~100 instructions per set.
+template <int N>
+__device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned char* dob, int t, float& my_off) {
+  constexpr int NP = N / 2, PITCH = N + 1, IMGB = N * PITCH * 8;     // bytes per {S,Q} image
+  constexpr int DB = N * 4, OB = NP * 4;                             // bytes per D / O image
+  constexpr int O_OFF = 2 * DB, DUMMY = 2 * DB + 2 * OB;             // dob layout: D[2][N], O[2][NP], dummy[N]
+  const int k = t / NP, l = t % NP;
+  {
+    float* Dg = reinterpret_cast<float*>(dob);
+    float* Og = reinterpret_cast<float*>(dob + O_OFF);
+    const f32x2* SQ = reinterpret_cast<const f32x2*>(sq);
+    for (int i = t; i < N; i += NP * NP) Dg[i] = SQ[i * PITCH + i][0];
+    for (int i = t; i < NP; i += NP * NP) Og[i] = SQ[i * PITCH + NP + i][0];          // set 0 pairs j with NP + j
+    __syncthreads();
+  }
+  const int row_pk = k * PITCH * 8, col_pl = l * 8;
+  const int a_pp = row_pk + col_pl;
+  int qk = NP + k, ql = NP + l;                                      // q index of set s: NP + ((j + s) & (NP - 1))
+  const int perm = ((t & (64 - NP)) | k) * 4;                        // ds_bpermute address of the lane with l == k
+  const int d_l = l * 4;                                             // D[.][p_l]
+  const int o_l = O_OFF + l * 4;                                     // O[.][l]
+  const int wd_pk = k == l ? k * 4 : DUMMY;                          // owner of D[.][p_k], D[.][q_k]
+  const bool own_d = k == l;
+  const int wo_k = l == ((k + 1) & (NP - 1)) ? O_OFF + k * 4 : DUMMY;  // owner of next set's O[.][k]
+  auto ldf = [&](const unsigned char* base, int off) { return *reinterpret_cast<const float*>(base + off); };
+  auto ld2 = [&](const unsigned char* base, int off) { return *reinterpret_cast<const f32x2*>(base + off); };
+  auto body = [&](auto CURC) {
+    constexpr int CUR = decltype(CURC)::value, NX = CUR ^ 1;
+    const unsigned char* C0 = sq + CUR * IMGB;
+    unsigned char* N0 = sq + NX * IMGB;
+    const int qlb = ql * 8, qkb = qk * (PITCH * 8);
+    const int a_pq = row_pk + qlb, a_qp = qkb + col_pl, a_qq = qkb + qlb;
+    const float lpp = ldf(dob + CUR * DB, d_l), lqq = ldf(dob + CUR * DB, ql * 4), lpq = ldf(dob + CUR * OB, o_l);
+    const f32x2 app = ld2(C0, a_pp), apq = ld2(C0, a_pq), aqp = ld2(C0, a_qp), aqq = ld2(C0, a_qq);
+    float cl, sl, offl;
+    jacobi_rotation(lpp, lqq, lpq, cl, sl, offl);
+    my_off = fmaxf(my_off, offl);
+    const float ck = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm, __builtin_bit_cast(int, cl)));
+    const float sk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm, __builtin_bit_cast(int, sl)));
+    // columns (pair l) on S and Q, then rows (pair k) on S
+    const float ypp = cl * app[0] - sl * apq[0], ypq = sl * app[0] + cl * apq[0];
+    const float yqp = cl * aqp[0] - sl * aqq[0], yqq = sl * aqp[0] + cl * aqq[0];
+    f32x2 npp, npq, nqp, nqq;
+    npp[1] = cl * app[1] - sl * apq[1];  npq[1] = sl * app[1] + cl * apq[1];
+    nqp[1] = cl * aqp[1] - sl * aqq[1];  nqq[1] = sl * aqp[1] + cl * aqq[1];
+    npp[0] = ck * ypp - sk * yqp;  npq[0] = ck * ypq - sk * yqq;
+    nqp[0] = sk * ypp + ck * yqp;  nqq[0] = sk * ypq + ck * yqq;
+    *reinterpret_cast<f32x2*>(N0 + a_pp) = npp;  *reinterpret_cast<f32x2*>(N0 + a_pq) = npq;
+    *reinterpret_cast<f32x2*>(N0 + a_qp) = nqp;  *reinterpret_cast<f32x2*>(N0 + a_qq) = nqq;
+    *reinterpret_cast<float*>(dob + NX * DB + wd_pk) = npp[0];
+    *reinterpret_cast<float*>(dob + NX * DB + (own_d ? qk * 4 : DUMMY)) = nqq[0];
+    *reinterpret_cast<float*>(dob + NX * OB + wo_k) = npq[0];        // S[p_k][q_k] of the next set
+    qk = NP | ((qk + 1) & (NP - 1));
+    ql = NP | ((ql + 1) & (NP - 1));
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int s = 0; s < NP; s += 2) {
+    body(std::integral_constant<int, 0>{});
+    body(std::integral_constant<int, 1>{});
+  }
+  return 0;                                                          // NP is even: the result is back in image 0
+}
+
 // measured (tools/probe/jacobi_probe.hip): more blocks per thread is SLOWER (N = 64: 1761 / 1930 / 2412 / 3643 cycles per
 // set for KB = 1 / 2 / 4 / 8; with two blocks resident per CU 2910 vs 3010) -- fewer waves hide less LDS latency -- so KB = 1
 template <int M2> struct JacobiCfg { static constexpr int KB = 1; static constexpr int NT = (M2 / 2) * (M2 / 2) / KB; };
@@ -640,7 +714,8 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
   float my_off = 0.f;
   __syncthreads();
   float* DO = jsm + 4 * M2 * PITCH;                   // after the two float2 images
-  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, my_off) : jacobi_sets<SWEEP_CROSS, M2, KB>(SQ, DO, tid, my_off);
+  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, my_off)
+                           : jacobi_cross_sets<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(DO), tid, my_off);
   float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
   for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
   for (int o = 32; o > 0; o >>= 1) my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
@@ -820,7 +895,7 @@ template <int M2>
 static void jacobi_enqueue_sweep(const JacobiGroup* grp, int ngrp, int C) {
   constexpr int B = M2 / 2;
   const int nblk = C / B, npair = nblk / 2;
-  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2) + 3 * M2 * sizeof(float);
+  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2) + 4 * M2 * sizeof(float);     // images, D[2][M2], O[2][M2/2], dummy[M2]
   // step -1 rotates the pairs inside each block, steps 0.. the cross pairs of every block pair:
   // each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
   for (int step = -1; step < nblk - 1; ++step)
