@@ -387,3 +387,43 @@ def test_wct_facade_from_tf_checkpoint_dirs(tmp_path, weights):
     assert np.array_equal(a, b)
     with pytest.raises(Exception, match='No checkpoint found for target relu1_1'):
         WCT(checkpoints=[dirs[0], str(tmp_path)], relu_targets=targets, vgg_path=vgg)
+
+
+def test_two_contexts_two_threads_and_no_memory_growth(weights):
+    """Two contexts (two HIP streams) driven concurrently by two host threads give the frames of a serial run
+    (thread-local error/flag state, per-context arenas); and once the arenas have seen the largest shapes,
+    further calls at any smaller or equal shape allocate nothing (no growth of device memory)."""
+    import threading
+    import torch
+    from wct_tf_amd.context import Context
+    targets = ['relu4_1', 'relu2_1', 'relu1_1']
+    ctxs = [Context(0), Context(0)]
+    for c in ctxs:
+        c.set_weights(weights)
+    jobs = [[(synthetic_image(800 + 10 * t + i, 48 + 8 * i, 64), synthetic_image(900 + 10 * t + i, 40, 56)) for i in range(3)]
+            for t in range(2)]
+    serial = [[ctxs[0].stylize(c, s, targets, alpha=0.8) for c, s in jobs[t]] for t in range(2)]
+    got = [None, None]
+
+    def work(t):
+        got[t] = [ctxs[t].stylize(c, s, targets, alpha=0.8) for c, s in jobs[t] for _ in range(1)]
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for t in range(2):
+        for a, b in zip(got[t], serial[t]):
+            assert np.array_equal(a, b)
+    # memory: after the runs above every shape has been seen by ctxs[0]
+    ctxs[0].sync(); ctxs[1].sync()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        for c, s in jobs[0] + jobs[1]:
+            ctxs[0].stylize(c, s, targets, alpha=0.8)
+    ctxs[0].sync()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    for c in ctxs:
+        c.close()

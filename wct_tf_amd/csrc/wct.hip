@@ -108,8 +108,17 @@ __global__ void colsum_finish_kernel(const float* partial, float* out, int C, in
   if (skip_style_mat(mat, shared_style)) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f;
-  for (int i = 0; i < nslab; ++i) s += partial[((size_t)mat * nslab + i) * C + c];
+  // eight independent partial sums keep eight loads in flight (a single dependent chain of up to 256 L2
+  // round trips made this trivial kernel take 65 us); the order is fixed, so the result is reproducible
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* pp = partial + (size_t)mat * nslab * C + c;
+  int i = 0;
+  for (; i + 8 <= nslab; i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += pp[(size_t)(i + j) * C];
+  }
+  for (; i < nslab; ++i) a[i & 7] += pp[(size_t)i * C];
+  const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   out[mat * C + c] = s / ((mat & 1) == 0 ? d0 : d1);
 }
 
