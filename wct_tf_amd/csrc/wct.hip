@@ -1362,12 +1362,16 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       // The eigensolver alternates a latency-bound kernel on a few workgroups (pair problems) with a
       // chip-wide tile update.  Splitting the batch into groups on separate streams lets one group's
       // pair problems hide under the other groups' tile updates.
-      // measured: splitting pays while a group still has few matrices (batch 8: 4 groups 22.3 ms vs 1 group
-      // 23.8 ms); at batch 16 one group is best (22.8 vs 24.1 ms with 4: twice the launches, no idle CUs to fill)
+      // measured per 5-level step: batch 8: 4 groups 22.3 ms vs 1 group 23.8; batch 16: 1 group 23.2, 2 groups 23.1,
+      // 3 groups 23.5; batch 32 (64 matrices): 1 group 35.1, 2 groups 33.0, 3 groups 33.3 -- the pair kernel spends
+      // 45 % of its wave cycles waiting, which the other group's bandwidth-bound tile update can fill
       int ngrp = nside + 1;
       if (ngrp > P) ngrp = P;
-      if (ngrp > 16 / P) ngrp = 16 / P < 1 ? 1 : 16 / P;
+      if (P > 16) ngrp = ngrp < 2 ? ngrp : 2;
+      else if (ngrp > 16 / P) ngrp = 16 / P < 1 ? 1 : 16 / P;
       if (ngrp > 4) ngrp = 4;
+      static const int force_ngrp = getenv("WCT_EIG_NGRP") ? atoi(getenv("WCT_EIG_NGRP")) : 0;   // tuning switch
+      if (force_ngrp >= 1 && force_ngrp <= 4 && force_ngrp <= nside + 1) ngrp = force_ngrp;
       JacobiGroup grp[4];
       HIP_TRY(hipEventRecord(ev_fork, s));
       size_t off = 0;
