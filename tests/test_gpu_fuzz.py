@@ -1,0 +1,107 @@
+"""Randomised GPU parity sweep (hypothesis, derandomised so every run sees the same cases): shapes, ranges and
+parameters the hand-written cases do not enumerate -- every call through the C ABI, checked against the CPU oracle.
+
+What the sweep is after:
+  * WCT: any C in {32..256 step 32}, ragged / tiny pixel counts (N >= 2, N < C included), feature scales from 1e-3
+    to 1e3 (the covariance and apply GEMMs split their operands into fp16 hi+lo pairs after a per-matrix
+    power-of-two scaling: the result must not depend on the magnitude of the input), both semantics, any alpha;
+  * AdaIN: same shapes;
+  * conv3x3: any H, W >= 2, channel counts from the path, with and without the folded upsample / ReLU;
+  * CORAL: arbitrary image sizes (exact integer moments)."""
+import numpy as np
+import pytest
+
+hypothesis = pytest.importorskip('hypothesis')
+from hypothesis import given, settings, strategies as st, HealthCheck  # noqa: E402
+
+import oracle  # noqa: E402
+from conftest import rel_err, max_rel  # noqa: E402
+from wct_tf_amd import _lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from wct_tf_amd.context import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def features(rng, n, c, scale, mix=True):
+    g = rng.standard_normal((n, c))
+    if mix:
+        g = g @ (rng.standard_normal((c, c)) / np.sqrt(c))
+    g = np.maximum(g, 0) * 10.0 ** rng.uniform(-0.7, 0.7, c)
+    return np.float32(g * scale)
+
+
+@settings(max_examples=30, **COMMON)
+@given(c=st.sampled_from([32, 64, 96, 128, 160, 256]), hc=st.integers(2, 26), wc=st.integers(2, 26),
+       hs=st.integers(2, 26), ws=st.integers(2, 26),
+       alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['np', 'tf']), log_scale=st.floats(-3.0, 3.0),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
+    rng = np.random.default_rng(seed)
+    scale = 10.0 ** log_scale
+    nc, ns = hc * wc, hs * ws
+    fc, fs = features(rng, nc, c, scale), features(rng, ns, c, scale * 10.0 ** rng.uniform(-1, 1))
+    want = (oracle.wct_np if mode == 'np' else oracle.wct_tf)(fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c), alpha)
+    want = np.asarray(want).reshape(nc, c)
+    got = ctx.transform(fc, fs, alpha, _lib.WCT_NP if mode == 'np' else _lib.WCT_TF)
+    # at tiny scales the reference's absolute 1e-5 eigenvalue cut-off decides which directions survive; an
+    # eigenvalue within fp32 noise of the cut-off may fall on either side -- compare where that cannot happen
+    cov = np.cov(np.float64(fc).T) if nc > 1 else np.zeros((c, c))
+    ev = np.linalg.eigvalsh(cov + (1e-8 if mode == 'tf' else 0) * np.eye(c))
+    near_cut = np.any(np.abs(ev - 1e-5) < 2e-6 + 1e-4 * np.abs(ev).max() * 1e-2)
+    if near_cut and alpha > 0:
+        return
+    assert np.all(np.isfinite(got))
+    assert rel_err(got, want) < 1e-3, (c, nc, ns, alpha, mode, log_scale)
+
+
+@settings(max_examples=15, **COMMON)
+@given(c=st.sampled_from([4, 32, 64, 128, 512]), hc=st.integers(2, 30), wc=st.integers(2, 30),
+       hs=st.integers(2, 30), ws=st.integers(2, 30),
+       alpha=st.floats(0.0, 1.0), log_scale=st.floats(-2.0, 2.0), seed=st.integers(0, 2 ** 31 - 1))
+def test_adain_random_shapes(ctx, c, hc, wc, hs, ws, alpha, log_scale, seed):
+    rng = np.random.default_rng(seed)
+    nc, ns = hc * wc, hs * ws
+    fc, fs = features(rng, nc, c, 10.0 ** log_scale, mix=False), features(rng, ns, c, 10.0 ** log_scale, mix=False)
+    want = np.asarray(oracle.adain(fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c), alpha)).reshape(nc, c)
+    got = ctx.adain(fc, fs, alpha)
+    assert rel_err(got, want) < 1e-4 and max_rel(got, want) < 1e-3
+
+
+@settings(max_examples=25, **COMMON)
+@given(h=st.integers(2, 70), w=st.integers(2, 70), cin=st.sampled_from([64, 128, 256]),
+       cout=st.sampled_from([64, 128, 256]), relu=st.booleans(), up=st.booleans(), seed=st.integers(0, 2 ** 31 - 1))
+def test_conv3x3_random_shapes(ctx, h, w, cin, cout, relu, up, seed):
+    rng = np.random.default_rng(seed)
+    x = np.maximum(rng.standard_normal((h, w, cin)), 0).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    got = ctx.conv3x3(x, wt, b, relu=relu, upsample=up)
+    xin = oracle.upsample2x_nearest(x) if up else x
+    h16 = lambda a: np.asarray(a, np.float16).astype(np.float32)   # noqa: E731
+    want = oracle.conv3x3_reflect(h16(xin), h16(wt), b, relu)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 2e-4 and max_rel(got, want) < 1e-3, (h, w, cin, cout, relu, up)
+
+
+@settings(max_examples=12, **COMMON)
+@given(hs=st.integers(1, 90), ws=st.integers(1, 90), ht=st.integers(1, 90), wt=st.integers(1, 90),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_coral_random_sizes(ctx, hs, ws, ht, wt, seed):
+    from wct_tf_amd.ops import preserve_colors_np
+    rng = np.random.default_rng(seed)
+    style = rng.integers(0, 256, (hs, ws, 3), dtype=np.uint8)
+    content = rng.integers(0, 256, (ht, wt, 3), dtype=np.uint8)
+    if hs * ws < 4 or ht * wt < 4:
+        return                                    # degenerate covariances: the reference divides by zero / inverts a singular matrix
+    want = oracle.preserve_colors_np(style, content)
+    got = preserve_colors_np(style, content, ctx=ctx)
+    assert got.shape == want.shape
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
