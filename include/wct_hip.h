@@ -128,6 +128,24 @@ int wct_stylize_batch_dev(wct_ctx* ctx, const uint8_t* content_dev, int Hc, int 
                           const int* levels, int n_levels, float alpha, unsigned flags,
                           uint8_t* out_dev);
 
+/* ---- decoder training (model.py:123-223, train.py:129-196) ---------------------------
+ * One optimiser step of the decoder for relu<level>_1 (the encoder is frozen, model.py:202):
+ *   F = enc(x); D = dec(F); F' = enc(D);
+ *   loss = feature_weight * mse(F', F) + pixel_weight * mse(D, x) + tv_weight * mean_b(total_variation(D))
+ *   Adam(lr, beta1, beta2, eps) on the decoder's kernels and biases (tf.train.AdamOptimizer, model.py:199).
+ * images: host fp32 [B][H][W][3] in [0,1] (train.py:72-83), H and W multiples of 2^(level-1).
+ * step: 1-based step number (Adam bias correction); lr: the already decayed rate (torch_decay, model.py:17-19);
+ * lr == 0 computes losses and gradients without touching the weights.  losses_out[4] = feature, pixel, tv, total.
+ * Forward in the inference precision (fp16 activations, fp32 accumulate), backward and optimiser in fp32. */
+int wct_train_step(wct_ctx* ctx, int level, const float* images, int B, int H, int W,
+                   float feature_weight, float pixel_weight, float tv_weight,
+                   float lr, float beta1, float beta2, float eps, int step, float* losses_out);
+/* conv `layer` (0-based, the 3-channel output conv last) of the decoder for relu<level>_1: its current fp32
+ * weights [3][3][Cin][Cout] / bias, and the gradients of the last wct_train_step.  Any pointer may be NULL.
+ * This is what a checkpoint writer (tf.train.Saver.save, train.py:183-185) reads. */
+int wct_get_decoder_layer(wct_ctx* ctx, int level, int layer, float* w_hwio, float* bias,
+                          float* grad_w, float* grad_b);
+
 /* ---- device memory helpers (thin wrappers so callers need no HIP binding) ----------- */
 int wct_dev_alloc(wct_ctx* ctx, size_t bytes, void** out);
 int wct_dev_free(wct_ctx* ctx, void* p);

@@ -118,6 +118,19 @@ def test_video_cli_flags_match_reference(tmp_path):
         ['frame_1.png', 'frame_2.png', 'frame_10.png', 'frame_11.png']
 
 
+def test_train_cli_flags_match_reference():
+    from wct_tf_amd.train import build_parser, torch_decay
+    flags = {a for act in build_parser()._actions for a in act.option_strings}
+    for f in ['--checkpoint', '--log-path', '--relu-target', '--content-path', '--val-path', '--vgg-path',
+              '--feature-weight', '--pixel-weight', '--tv-weight', '--learning-rate', '--lr-decay', '--max-iter',
+              '--batch-size', '--save-iter', '--summary-iter', '--max-to-keep']:
+        assert f in flags, f                                   # train.py:12-57
+    d = build_parser().parse_args(['--checkpoint', 'x', '--relu-target', 'relu3_1'])
+    assert (d.feature_weight, d.pixel_weight, d.tv_weight, d.learning_rate, d.lr_decay, d.max_iter, d.batch_size,
+            d.save_iter, d.summary_iter, d.max_to_keep) == (1, 1, 0, 1e-4, 0, 16000, 8, 200, 20, 10)
+    assert torch_decay(1e-4, 0, 5e-5) == 1e-4 and abs(torch_decay(1e-4, 20000, 5e-5) - 5e-5) < 1e-12   # ops.py:298-309
+
+
 def test_t7_reader_matches_reference_torchfile():
     """wct_tf_amd/t7.py on tests/golden/tiny_vgg.t7 == what the reference's torchfile.py + the
     vgg_normalised.py:22-34 walk extracted from the same file (fixture made by oracle/make_golden.py)."""

@@ -43,6 +43,9 @@ SIGNATURES = [
                               C.c_float, C.c_uint, _U8]),
     ('wct_stylize_batch_dev', C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _I,
                                         C.c_int, C.c_float, C.c_uint, _P]),
+    ('wct_train_step', C.c_int, [_P, C.c_int, _F, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _F]),
+    ('wct_get_decoder_layer', C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F]),
     ('wct_dev_alloc', C.c_int, [_P, C.c_size_t, _PP]),
     ('wct_dev_free', C.c_int, [_P, _P]),
     ('wct_h2d', C.c_int, [_P, _P, _P, C.c_size_t]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libwct_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'wct.hip', 'coral.hip']
+SOURCES = ['api.hip', 'conv.hip', 'wct.hip', 'coral.hip', 'train.hip']
 
 
 def needs_build():

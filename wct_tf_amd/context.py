@@ -257,6 +257,36 @@ class Context(object):
                 self.dev_free(p)
         return out
 
+    # ---- decoder training (model.py:123-223) --------------------------------
+    def train_step(self, relu_target, images01, step, learning_rate=1e-4, feature_weight=1.0, pixel_weight=1.0,
+                   tv_weight=0.0, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """One Adam step on the decoder of `relu_target`; images01 [B][H][W][3] fp32 in [0,1].
+        Returns {'feature_loss', 'pixel_loss', 'tv_loss', 'total_loss'}.  learning_rate=0 only evaluates."""
+        level = _levels([relu_target])[0]
+        x = f32(images01)
+        assert x.ndim == 4 and x.shape[3] == 3
+        out = (C.c_float * 4)()
+        check(self.lib.wct_train_step(self.h, level, x.ctypes.data_as(_lib._F), x.shape[0], x.shape[1], x.shape[2],
+                                      float(feature_weight), float(pixel_weight), float(tv_weight), float(learning_rate),
+                                      float(beta1), float(beta2), float(epsilon), int(step), out))
+        return {'feature_loss': out[0], 'pixel_loss': out[1], 'tv_loss': out[2], 'total_loss': out[3]}
+
+    def get_decoder(self, relu_target, grads=False):
+        """[(w HWIO fp32, b)] of the decoder as it is now on the device (after training steps); with grads=True
+        the gradients of the last train_step instead."""
+        level = _levels([relu_target])[0]
+        out = []
+        for i, (_, cin, cout, _) in enumerate(p for p in decoder_plan('relu%d_1' % level) if p[0] == 'C'):
+            w = np.empty((3, 3, cin, cout), np.float32)
+            b = np.empty(cout, np.float32)
+            wp, bp = w.ctypes.data_as(_lib._F), b.ctypes.data_as(_lib._F)
+            if grads:
+                check(self.lib.wct_get_decoder_layer(self.h, level, i, None, None, wp, bp))
+            else:
+                check(self.lib.wct_get_decoder_layer(self.h, level, i, wp, bp, None, None))
+            out.append((w, b))
+        return out
+
     # ---- measurement -------------------------------------------------------
     def prof_enable(self, on=True):
         check(self.lib.wct_prof_enable(self.h, int(on)))

@@ -44,6 +44,10 @@ struct Decoder {
   std::vector<ConvLayer> convs;    // every conv but the last
   half_t* last_w = nullptr;        // MFMA A-fragments of the 64->3 conv (see ConvLastArgs::wfrag)
   float* last_b = nullptr;
+  // training (wct_train_step): fp32 master copies (HWIO), Adam moments and the last step's gradients, one entry
+  // per conv of the plan (the output conv last)
+  std::vector<float*> w32, b32, mw, vw, mb, vb, gw, gb;
+  std::vector<int> cin, cout;
 };
 
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
@@ -58,6 +62,9 @@ struct wct_ctx {
   half_t* first_w = nullptr;       // folded conv1_1 as fp16 hi/lo MFMA fragments (ConvFirstArgs::wfrag)
   float* first_b = nullptr;
   ConvLayer enc[12];               // conv1_2 .. conv5_1
+  float* first_w32 = nullptr;      // folded conv1_1 weights fp32 [27][64] (data gradient of the feature loss)
+  float* enc_wt[12] = {nullptr};   // encoder weights transposed [(tap, cout)][cin] fp32 (B operand of the dgrad GEMM)
+  DevBuf train_ws;
   Decoder dec[6];
   DevBuf act[2], feat_c, feat_s[6], img_c, img_s, img_t[2], wct_out, wct_ws, stage[4];
   float ss_alpha = 0.6f;           // style-swap settings (stylize.py:34-37 defaults)
@@ -152,6 +159,8 @@ static void free_layer(ConvLayer& l) {
 }
 static void free_decoder(Decoder& d) {
   for (auto& l : d.convs) free_layer(l);
+  for (auto* v : {&d.w32, &d.b32, &d.mw, &d.vw, &d.mb, &d.vb, &d.gw, &d.gb})
+    for (float* p : *v) if (p) hipFree(p);
   if (d.last_w) hipFree(d.last_w);
   if (d.last_b) hipFree(d.last_b);
   d = Decoder();
@@ -163,6 +172,9 @@ extern "C" void wct_destroy(wct_ctx* c) {
   hipStreamSynchronize(c->stream);
   if (c->first_w) hipFree(c->first_w);
   if (c->first_b) hipFree(c->first_b);
+  if (c->first_w32) hipFree(c->first_w32);
+  for (int i = 0; i < 12; ++i) if (c->enc_wt[i]) hipFree(c->enc_wt[i]);
+  if (c->train_ws.p) hipFree(c->train_ws.p);
   for (auto& l : c->enc) free_layer(l);
   for (auto& d : c->dec) free_decoder(d);
   DevBuf* bufs[] = {&c->act[0], &c->act[1], &c->feat_c, &c->img_c, &c->img_s, &c->img_t[0], &c->img_t[1],
@@ -316,7 +328,18 @@ extern "C" int wct_set_encoder(wct_ctx* c, const float* pre_w, const float* pre_
         }
   TRY(upload(c, frag.data(), frag.size() * sizeof(half_t), (void**)&c->first_w));
   TRY(upload(c, fb.data(), fb.size() * sizeof(float), (void**)&c->first_b));
-  for (int i = 0; i < 12; ++i) TRY(pack_conv(c, w[i + 1], b[i + 1], ENC_CIN[i], ENC_COUT[i], &c->enc[i]));
+  if (c->first_w32) { hipFree(c->first_w32); c->first_w32 = nullptr; }
+  TRY(upload(c, fw.data(), fw.size() * sizeof(float), (void**)&c->first_w32));
+  for (int i = 0; i < 12; ++i) {
+    TRY(pack_conv(c, w[i + 1], b[i + 1], ENC_CIN[i], ENC_COUT[i], &c->enc[i]));
+    const int cin = ENC_CIN[i], cout = ENC_COUT[i];
+    std::vector<float> wt((size_t)9 * cin * cout);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int ci = 0; ci < cin; ++ci)
+        for (int co = 0; co < cout; ++co) wt[((size_t)tap * cout + co) * cin + ci] = w[i + 1][((size_t)tap * cin + ci) * cout + co];
+    if (c->enc_wt[i]) { hipFree(c->enc_wt[i]); c->enc_wt[i] = nullptr; }
+    TRY(upload(c, wt.data(), wt.size() * sizeof(float), (void**)&c->enc_wt[i]));
+  }
   c->enc_loaded = true;
   return WCT_OK;
 }
@@ -371,6 +394,12 @@ extern "C" int wct_set_decoder(wct_ctx* c, int level, const float* const* w, con
     } else {
       d.convs.emplace_back();
       TRY(pack_conv(c, w[i], b[i], s.cin, s.cout, &d.convs.back()));
+    }
+    {
+      float *w32 = nullptr, *b32 = nullptr;
+      TRY(upload(c, w[i], (size_t)9 * s.cin * s.cout * sizeof(float), (void**)&w32));
+      TRY(upload(c, b[i], (size_t)s.cout * sizeof(float), (void**)&b32));
+      d.w32.push_back(w32); d.b32.push_back(b32); d.cin.push_back(s.cin); d.cout.push_back(s.cout);
     }
     ++i;
   }
@@ -798,4 +827,248 @@ extern "C" int wct_stylize(wct_ctx* c, const uint8_t* content, int Hc, int Wc, c
   TRY(wct_stylize_batch_dev(c, (uint8_t*)dc, Hc, Wc, (uint8_t*)ds, Hs, Ws, 1, levels, n_levels, alpha, flags,
                             (uint8_t*)c->stage[2].p));
   return fetch(c, out, c->stage[2].p, (size_t)Ho * Wo * 3);
+}
+
+// ---------------------------------------------------------------------------
+// decoder training (model.py:123-223, train.py:129-196): one optimiser step
+// ---------------------------------------------------------------------------
+namespace {
+struct TrainArena {
+  char* base; size_t off;
+  template <typename T> T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (n * sizeof(T) + 255) & ~(size_t)255;
+    return p;
+  }
+};
+struct EncStep { int idx; int h, w; half_t* out; half_t* pooled; int ph, pw; };      // idx into enc[]; (h, w) conv dims
+struct DecStep { int conv; int up; int h, w; const half_t* in; half_t* out; };       // (h, w) = conv output dims
+}  // namespace
+
+// images: host fp32 [B][H][W][3] in [0,1] (train.py:72-83).  losses_out[4] = feature, pixel, tv, total (host).
+// step = 1-based optimiser step (Adam bias correction); lr is the already decayed learning rate (model.py:17-19).
+extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B, int H, int W,
+                              float feature_weight, float pixel_weight, float tv_weight,
+                              float lr, float beta1, float beta2, float eps, int step, float* losses_out) {
+  ARG_CHECK(c && images && losses_out && level >= 1 && level <= 5 && B >= 1 && B <= 64 && step >= 1);
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->enc_loaded) { wct_set_error("encoder weights not set (wct_set_encoder)"); return WCT_ERR_STATE; }
+  Decoder& d = c->dec[level];
+  if (!d.loaded) { wct_set_error("decoder weights for relu%d_1 not set (wct_set_decoder)", level); return WCT_ERR_STATE; }
+  const int scale = 1 << (level - 1);
+  ARG_CHECK(H % scale == 0 && W % scale == 0 && H / scale >= 2 && W / scale >= 2);   // the decoder returns exactly H x W
+  hipStream_t s = c->stream;
+  const int C = LEVEL_C[level];
+  const int h = H / scale, w = W / scale;
+  const int nconv = (int)d.w32.size();
+  static const int seq_tap[12] = {0, 2, 0, 3, 0, 0, 0, 4, 0, 0, 0, 5};
+  static const int pool_after[12] = {1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0};
+  int tap_idx = -1;
+  for (int i = 0; i < 12 && level > 1; ++i) if (seq_tap[i] == level) tap_idx = i;
+
+  // optimiser state, allocated on first use
+  if (d.mw.empty()) {
+    for (int i = 0; i < nconv; ++i) {
+      const size_t nw = (size_t)9 * d.cin[i] * d.cout[i];
+      float* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      const size_t bytes[6] = {nw * 4, nw * 4, (size_t)d.cout[i] * 4, (size_t)d.cout[i] * 4, nw * 4, (size_t)d.cout[i] * 4};
+      for (int k = 0; k < 6; ++k) { HIP_TRY(hipMalloc((void**)&p[k], bytes[k])); HIP_TRY(hipMemsetAsync(p[k], 0, bytes[k], s)); }
+      d.mw.push_back(p[0]); d.vw.push_back(p[1]); d.mb.push_back(p[2]); d.vb.push_back(p[3]); d.gw.push_back(p[4]); d.gb.push_back(p[5]);
+    }
+  }
+
+  // ---- carve the workspace (first pass sizes, second pass pointers)
+  std::vector<EncStep> enc_steps;
+  std::vector<DecStep> dec_steps;
+  float *X = nullptr, *F = nullptr, *Fp = nullptr, *D = nullptr, *g0 = nullptr, *g1 = nullptr, *col = nullptr, *gp = nullptr,
+        *partial = nullptr, *wt = nullptr, *dloss = nullptr;
+  half_t *A0 = nullptr, *e0 = nullptr;
+  double* lpart = nullptr;
+  size_t total = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) TRY(ensure(c, c->train_ws, total));
+    TrainArena ar = {pass ? (char*)c->train_ws.p : nullptr, 0};
+    enc_steps.clear(); dec_steps.clear();
+    size_t gmax = (size_t)B * H * W * 64, colmax = 0, gpmax = 0, partmax = 256 * 512, wtmax = 0;
+    X = ar.take<float>((size_t)B * H * W * 3);
+    F = ar.take<float>((size_t)B * h * w * C);
+    Fp = ar.take<float>((size_t)B * h * w * C);
+    A0 = ar.take<half_t>((size_t)B * h * w * C);
+    D = ar.take<float>((size_t)B * H * W * 3);
+    // decoder activations
+    {
+      int hh = h, ww = w, up = 0, ci = 0;
+      const half_t* cur = A0;
+      for (auto& st : d.plan) {
+        if (st.kind == 'U') { up = 1; hh *= 2; ww *= 2; continue; }
+        half_t* out = st.cout == 3 ? nullptr : ar.take<half_t>((size_t)B * hh * ww * st.cout);
+        dec_steps.push_back({ci, up, hh, ww, cur, out});
+        const size_t px = (size_t)B * hh * ww, pxp = (size_t)B * (hh + 2) * (ww + 2);
+        colmax = std::max(colmax, std::max(px * 9 * st.cin, pxp * 9 * st.cout));
+        gpmax = std::max(gpmax, pxp * st.cin);
+        gmax = std::max(gmax, std::max(px * st.cin, px * (size_t)std::max(st.cout, 4)));
+        partmax = std::max(partmax, (size_t)conv_wgrad_splits(B, hh, ww) * 9 * st.cin * st.cout);
+        wtmax = std::max(wtmax, (size_t)9 * st.cin * st.cout);
+        cur = out; up = 0; ++ci;
+      }
+    }
+    // encoder pass over the decoded image, every activation kept
+    e0 = ar.take<half_t>((size_t)B * H * W * 64);
+    {
+      int hh = H, ww = W;
+      colmax = std::max(colmax, (size_t)B * (hh + 2) * (ww + 2) * 9 * 64);
+      gpmax = std::max(gpmax, (size_t)B * (hh + 2) * (ww + 2) * 64);
+      for (int i = 0; i <= tap_idx; ++i) {
+        const int cout = ENC_COUT[i], cin = ENC_CIN[i];
+        EncStep es = {i, hh, ww, nullptr, nullptr, 0, 0};
+        if (i != tap_idx) es.out = ar.take<half_t>((size_t)B * hh * ww * cout);
+        const size_t pxp = (size_t)B * (hh + 2) * (ww + 2);
+        colmax = std::max(colmax, pxp * 9 * cout);
+        gpmax = std::max(gpmax, pxp * cin);
+        gmax = std::max(gmax, (size_t)B * hh * ww * std::max(cin, cout));
+        if (pool_after[i] && i != tap_idx) {
+          es.ph = (hh + 1) / 2; es.pw = (ww + 1) / 2;
+          es.pooled = ar.take<half_t>((size_t)B * es.ph * es.pw * cout);
+          hh = es.ph; ww = es.pw;
+        }
+        enc_steps.push_back(es);
+      }
+    }
+    g0 = ar.take<float>(gmax); g1 = ar.take<float>(gmax);
+    col = ar.take<float>(colmax); gp = ar.take<float>(gpmax);
+    partial = ar.take<float>(partmax); wt = ar.take<float>(wtmax);
+    lpart = ar.take<double>(1024); dloss = ar.take<float>(4);
+    total = ar.off;
+  }
+
+  // ---- forward
+  HIP_TRY(hipMemcpyAsync(X, images, (size_t)B * H * W * 3 * sizeof(float), hipMemcpyHostToDevice, s));
+  {
+    float* taps[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    taps[level] = F;
+    TRY(run_encoder(c, X, B, H, W, 0, level, taps));                       // content features (the target of the feature loss)
+  }
+  TRY(launch_f32_to_f16(F, A0, (size_t)B * h * w * C, s));
+  for (auto& ds : dec_steps) {
+    const int cin = d.cin[ds.conv], cout = d.cout[ds.conv];
+    if (cout == 3) {
+      ConvLastArgs a;
+      a.x = ds.in; a.wfrag = d.last_w; a.bias = d.last_b; a.y = D; a.B = B; a.H = ds.h; a.W = ds.w;
+      TRY(launch_conv_last(a, s));
+    } else {
+      TRY(run_conv(c, d.convs[ds.conv], ds.in, ds.out, nullptr, B, ds.h, ds.w, ds.up, 1));
+    }
+    (void)cin;
+  }
+  {  // encoder over the decoded image (not clipped in training: model.py:176), pools as separate kernels
+    ConvFirstArgs a;
+    a.x = D; a.wfrag = c->first_w; a.bias = c->first_b; a.y16 = level > 1 ? e0 : nullptr; a.y32 = level == 1 ? Fp : nullptr;
+    a.B = B; a.H = H; a.W = W; a.clamp01 = 0;
+    TRY(launch_conv_first(a, s));
+    const half_t* cur = e0;
+    for (auto& es : enc_steps) {
+      const bool last = es.idx == tap_idx;
+      TRY(run_conv(c, c->enc[es.idx], cur, last ? nullptr : es.out, last ? Fp : nullptr, B, es.h, es.w, 0, 1));
+      cur = es.out;
+      if (es.pooled) { TRY(launch_maxpool2x2(es.out, es.pooled, B, es.h, es.w, ENC_COUT[es.idx], s)); cur = es.pooled; }
+    }
+  }
+
+  // ---- losses and the gradient w.r.t. the decoded image
+  const size_t nF = (size_t)B * h * w * C, nD = (size_t)B * H * W * 3;
+  float* g = g0; float* gother = g1;
+  TRY(launch_mse(Fp, F, nF, feature_weight, g, 0, lpart, dloss + 0, s));     // g = d feature_loss / d F'
+  TRY(launch_relu_mask32(g, Fp, nF, s));
+  if (level == 1) {
+    TRY(launch_conv_first_dgrad(g, c->first_w32, gp, B, H, W, s));
+  } else {
+    for (int k = (int)enc_steps.size() - 1; k >= 0; --k) {
+      const EncStep& es = enc_steps[k];
+      const int cin = ENC_CIN[es.idx], cout = ENC_COUT[es.idx];
+      TRY(launch_conv_dgrad(g, c->enc_wt[es.idx], B, es.h, es.w, cin, cout, col, gp, gother, s));   // w.r.t. the conv input
+      std::swap(g, gother);
+      if (k > 0) {
+        const EncStep& pv = enc_steps[k - 1];
+        if (pv.pooled) {
+          TRY(launch_maxpool_adjoint(pv.out, g, gother, B, pv.h, pv.w, ENC_COUT[pv.idx], s));
+          std::swap(g, gother);
+        }
+        TRY(launch_relu_mask16(g, pv.out, (size_t)B * pv.h * pv.w * ENC_COUT[pv.idx], s));
+      } else {
+        TRY(launch_relu_mask16(g, e0, (size_t)B * H * W * 64, s));
+      }
+    }
+    TRY(launch_conv_first_dgrad(g, c->first_w32, gp, B, H, W, s));
+  }
+  TRY(launch_reflect_fold(gp, gother, B, H, W, 3, s));                       // d feature_loss / d D
+  g = gother; gother = (g == g0) ? g1 : g0;
+  TRY(launch_mse(D, X, nD, pixel_weight, g, 1, lpart, dloss + 1, s));        // += d pixel_loss / d D
+  TRY(launch_tv(D, B, H, W, 3, tv_weight, g, lpart, dloss + 2, s));           // += d tv_loss / d D
+
+  // ---- decoder backward: weight / bias gradients, data gradients down to the second conv
+  for (int k = (int)dec_steps.size() - 1; k >= 0; --k) {
+    const DecStep& ds = dec_steps[k];
+    const int cin = d.cin[ds.conv], cout = d.cout[ds.conv];
+    const size_t px = (size_t)B * ds.h * ds.w;
+    if (cout != 3) TRY(launch_relu_mask16(g, ds.out, px * cout, s));
+    TRY(launch_bias_grad(g, px, cout, partial, d.gb[ds.conv], s));
+    int cpad = cout;
+    if (cout == 3) {           // the GEMM operands want 16-byte rows: pad the 3-channel gradient to 4
+      TRY(launch_pad3to4(g, gother, px, s));
+      std::swap(g, gother);
+      cpad = 4;
+    }
+    TRY(launch_conv_wgrad(ds.in, ds.up, g, cpad, B, ds.h, ds.w, cin, cout, col, partial, conv_wgrad_splits(B, ds.h, ds.w), d.gw[ds.conv], s));
+    if (k > 0) {
+      TRY(launch_transpose_w(d.w32[ds.conv], wt, cin, cout, cpad, s));
+      TRY(launch_conv_dgrad(g, wt, B, ds.h, ds.w, cin, cpad, col, gp, gother, s));
+      std::swap(g, gother);
+      if (ds.up) {
+        TRY(launch_upsample_adjoint(g, gother, B, ds.h / 2, ds.w / 2, cin, s));
+        std::swap(g, gother);
+      }
+    }
+  }
+
+  // ---- Adam (model.py:199: beta1 0.9, beta2 0.999 in the reference), then refresh the fp16 forward weights
+  const float lr_t = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));
+  if (lr != 0.f) {
+    int ci = 0;
+    for (int i = 0; i < nconv; ++i) {
+      const size_t nw = (size_t)9 * d.cin[i] * d.cout[i];
+      TRY(launch_adam(d.w32[i], d.mw[i], d.vw[i], d.gw[i], nw, lr_t, beta1, beta2, eps, s));
+      TRY(launch_adam(d.b32[i], d.mb[i], d.vb[i], d.gb[i], (size_t)d.cout[i], lr_t, beta1, beta2, eps, s));
+      if (d.cout[i] == 3) {
+        TRY(launch_pack_last_frag(d.w32[i], d.last_w, s));
+        HIP_TRY(hipMemcpyAsync(d.last_b, d.b32[i], 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      } else {
+        ConvLayer& l = d.convs[ci++];
+        TRY(launch_pack_conv_frag(d.w32[i], l.w, l.cin, l.cout, s));
+        HIP_TRY(hipMemcpyAsync(l.b, d.b32[i], (size_t)l.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+    }
+  }
+  float hl[4];
+  HIP_TRY(hipMemcpyAsync(hl, dloss, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  losses_out[0] = hl[0]; losses_out[1] = hl[1]; losses_out[2] = hl[2]; losses_out[3] = hl[0] + hl[1] + hl[2];
+  return WCT_OK;
+}
+
+// the decoder's current fp32 weights (after training steps) and the gradients of the last wct_train_step,
+// conv `layer` of the plan (the output conv is the last); any pointer may be NULL
+extern "C" int wct_get_decoder_layer(wct_ctx* c, int level, int layer, float* w_hwio, float* bias, float* grad_w, float* grad_b) {
+  ARG_CHECK(c && level >= 1 && level <= 5);
+  HIP_TRY(hipSetDevice(c->device));
+  Decoder& d = c->dec[level];
+  if (!d.loaded) { wct_set_error("decoder weights for relu%d_1 not set (wct_set_decoder)", level); return WCT_ERR_STATE; }
+  ARG_CHECK(layer >= 0 && layer < (int)d.w32.size());
+  const size_t nw = (size_t)9 * d.cin[layer] * d.cout[layer] * sizeof(float), nb = (size_t)d.cout[layer] * sizeof(float);
+  if ((grad_w || grad_b) && d.gw.empty()) { wct_set_error("no training step has run for relu%d_1", level); return WCT_ERR_STATE; }
+  if (w_hwio) HIP_TRY(hipMemcpyAsync(w_hwio, d.w32[layer], nw, hipMemcpyDeviceToHost, c->stream));
+  if (bias) HIP_TRY(hipMemcpyAsync(bias, d.b32[layer], nb, hipMemcpyDeviceToHost, c->stream));
+  if (grad_w) HIP_TRY(hipMemcpyAsync(grad_w, d.gw[layer], nw, hipMemcpyDeviceToHost, c->stream));
+  if (grad_b) HIP_TRY(hipMemcpyAsync(grad_b, d.gb[layer], nb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return WCT_OK;
 }

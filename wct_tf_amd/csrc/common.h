@@ -80,6 +80,27 @@ int launch_f32_to_f16(const float* x, half_t* y, size_t n, hipStream_t s);
 int launch_f16_to_f32(const half_t* x, float* y, size_t n, hipStream_t s);
 
 // ---- wct.hip --------------------------------------------------------------
+// generic fp32 GEMM on v_mfma_f32_32x32x2_f32:  D[m][n] = sum_k A(m,k) B(k,n)
+// A element (m,k): a_kmajor ? A[k*lda+m] : A[m*lda+k];  B element (k,n): b_kmajor ? B[k*ldb+n] : B[n*ldb+k]
+struct GemmArgs {
+  const float* A; int lda; int a_kmajor;
+  const float* B; int ldb; int b_kmajor;
+  const float* a_sub_m;   // subtract vector indexed by m from A (cov centring)       or null
+  const float* b_sub_n;   // subtract vector indexed by n from B                      or null
+  const float* a_sub_k;   // subtract vector indexed by k from A (apply centring)     or null
+  const float* a_scale_k; // scale A by vector indexed by k (E diag(d))               or null
+  int M, N, K;
+  int ksplit;             // K elements per blockIdx.z slice (multiple of 16)
+  float* out32; half_t* out16; int ldo;
+  size_t out_split_stride;  // elements between K-slices of out32 (split-K partials)
+  const float* bias_n;    // added per output column or null
+  // batching: blockIdx.z = batch * nsplit + split; strides in elements (0 = shared)
+  int nsplit;
+  size_t sA, sB, s_sub_m, s_sub_n, s_sub_k, s_scale_k, s_out, s_bias;
+};
+
+int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s);
+
 // Feature matrices are pixel-major: X[n][c] (NHWC flattened), fp32.
 enum { WCT_MODE_NP = 0, WCT_MODE_TF = 1 };
 
@@ -108,6 +129,31 @@ size_t style_swap_workspace_bytes(int C, int hc, int wc, int hs, int ws, int pat
 int launch_style_swap(const float* content, int hc, int wc, const float* style, int hs, int ws, int C,
                       float alpha, int patch, int stride, float eps, half_t* out16, float* out32,
                       void* workspace, size_t workspace_bytes, hipStream_t s);
+
+// ---- train.hip ------------------------------------------------------------
+int launch_im2col_act(const half_t* x, float* col, int B, int H, int W, int C, int upsample, hipStream_t s);
+int launch_im2col_grad(const float* g, float* col, int B, int H, int W, int C, hipStream_t s);
+int launch_reflect_fold(const float* gp, float* g, int B, int H, int W, int C, hipStream_t s);
+int launch_relu_mask16(float* g, const half_t* act, size_t n, hipStream_t s);
+int launch_relu_mask32(float* g, const float* act, size_t n, hipStream_t s);
+int launch_upsample_adjoint(const float* gb, float* gs, int B, int h, int w, int C, hipStream_t s);
+int launch_maxpool_adjoint(const half_t* pre, const float* gpool, float* gpre, int B, int H, int W, int C, hipStream_t s);
+int launch_mse(const float* a, const float* b, size_t n, float weight, float* grad, int accumulate, double* partial,
+               float* loss_out, hipStream_t s);
+int launch_tv(const float* x, int B, int H, int W, int C, float weight, float* grad, double* partial, float* loss_out, hipStream_t s);
+int launch_bias_grad(const float* g, size_t rows, int C, float* partial, float* out, hipStream_t s);
+int launch_reduce_slabs(const float* partial, size_t n, int nslab, float* out, hipStream_t s);
+int launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
+int launch_pack_conv_frag(const float* w, half_t* frag, int cin, int cout, hipStream_t s);
+int launch_pack_last_frag(const float* w, half_t* frag, hipStream_t s);
+int launch_transpose_w(const float* w, float* wt, int cin, int cout, int cout_pad, hipStream_t s);
+int launch_pad3to4(const float* x, float* y, size_t n, hipStream_t s);
+int launch_conv_dgrad(const float* g, const float* wt, int B, int H, int W, int cin, int cout,
+                      float* col, float* gp, float* gin, hipStream_t s);
+int launch_conv_wgrad(const half_t* x16, int upsample, const float* g, int ldg, int B, int H, int W, int cin, int cout,
+                      float* col, float* partial, int nsplit, float* dw, hipStream_t s);
+int conv_wgrad_splits(int B, int H, int W);
+int launch_conv_first_dgrad(const float* g, const float* wf, float* gp, int B, int H, int W, hipStream_t s);
 
 // ---- coral.hip ------------------------------------------------------------
 struct CoralApplyArgs {

@@ -127,23 +127,6 @@ __global__ void colsum_finish_kernel(const float* partial, float* out, int C, in
 //   D[m][n] = sum_k A(m,k) B(k,n)
 // A element (m,k): a_kmajor ? A[k*lda+m] : A[m*lda+k];  B element (k,n): b_kmajor ? B[k*ldb+n] : B[n*ldb+k]
 // ---------------------------------------------------------------------------
-struct GemmArgs {
-  const float* A; int lda; int a_kmajor;
-  const float* B; int ldb; int b_kmajor;
-  const float* a_sub_m;   // subtract vector indexed by m from A (cov centring)       or null
-  const float* b_sub_n;   // subtract vector indexed by n from B                      or null
-  const float* a_sub_k;   // subtract vector indexed by k from A (apply centring)     or null
-  const float* a_scale_k; // scale A by vector indexed by k (E diag(d))               or null
-  int M, N, K;
-  int ksplit;             // K elements per blockIdx.z slice (multiple of 16)
-  float* out32; half_t* out16; int ldo;
-  size_t out_split_stride;  // elements between K-slices of out32 (split-K partials)
-  const float* bias_n;    // added per output column or null
-  // batching: blockIdx.z = batch * nsplit + split; strides in elements (0 = shared)
-  int nsplit;
-  size_t sA, sB, s_sub_m, s_sub_n, s_sub_k, s_scale_k, s_out, s_bias;
-};
-
 constexpr int GK = 16;
 
 // one operand tile (GK x BX, k-major in LDS) moves global -> registers -> LDS in two phases so the
@@ -274,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     }
 }
 
-static int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s) {
+int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s) {
   g.nsplit = nsplit;
   const int gz = nsplit * nbatch;
   if (g.M >= 128 && g.N >= 128) {
