@@ -169,8 +169,20 @@ def train(argv=None):
         x = train_q.get()
         lr = torch_decay(args.learning_rate, step, args.lr_decay)
         step += 1
-        results = ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
-                                 pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+        try:
+            results = ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
+                                     pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+            if not np.isfinite(results['total_loss']):
+                raise FloatingPointError('non-finite loss at step %d' % step)
+        except Exception as e:                     # noqa: BLE001  train.py:168-174: reload the latest checkpoint and go on
+            print(e)
+            print('Exception encountered, re-loading latest checkpoint')
+            restored, step_saved = load_latest(args.checkpoint, relu)
+            if restored is None:
+                raise
+            ctx.set_decoder(relu, restored)        # fresh optimiser state, as a restored graph would have saved ones
+            step = step_saved
+            continue
         rec = dict(results, step=step, lr=lr, time=time.time() - start)
         if iteration % args.summary_iter == 0:          # a validation batch, evaluated without an update
             val = ctx.train_step(relu, val_q.get(), step=step, learning_rate=0.0, feature_weight=args.feature_weight,
