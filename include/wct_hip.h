@@ -115,6 +115,8 @@ int wct_coral_apply(wct_ctx* ctx, const uint8_t* src, int H, int W, const double
 
 /* ---- the hot path: WCT.predict (wct.py:70-106) -------------------------------------
  * levels: relu levels in pipeline order, e.g. {5,4,3,2,1}.  Output size: wct_output_size. */
+/* Images must keep a feature map of at least 2x2 at the deepest level (every conv reflect-pads by one pixel, and
+ * tf.pad REFLECT refuses a 1-pixel map just the same): H, W >= 2^(level-1) + 1, else WCT_STATUS_ARG. */
 int wct_output_size(int Hc, int Wc, const int* levels, int n_levels, int* Ho, int* Wo);
 int wct_stylize(wct_ctx* ctx, const uint8_t* content, int Hc, int Wc,
                 const uint8_t* style, int Hs, int Ws,

@@ -105,3 +105,47 @@ def test_coral_random_sizes(ctx, hs, ws, ht, wt, seed):
     got = preserve_colors_np(style, content, ctx=ctx)
     assert got.shape == want.shape
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+@settings(max_examples=12, **COMMON)
+@given(hc=st.integers(16, 90), wc=st.integers(16, 90), hs=st.integers(16, 90), ws=st.integers(16, 90),
+       levels=st.lists(st.sampled_from([5, 4, 3, 2, 1]), min_size=1, max_size=4, unique=True),
+       alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['tf', 'np']), adain=st.booleans(), seed=st.integers(0, 1000))
+def test_fused_pipeline_equals_chained_ops_random(hc, wc, hs, ws, levels, alpha, mode, adain, seed):
+    """wct_stylize (one fused call: images resident, fp16 hand-over between the stages, pools fused into the convs)
+    against the same GPU ops chained through the layer-level ABI, bit for bit, on random sizes / level subsets."""
+    from wct_tf_amd.context import Context
+    from wct_tf_amd.weights import synthetic_weights, synthetic_image
+    levels = sorted(levels, reverse=True)
+    targets = ['relu%d_1' % l for l in levels]
+    global _PIPE
+    try:
+        _PIPE
+    except NameError:
+        _PIPE = Context(0)
+        _PIPE.set_weights(synthetic_weights(42))
+    ctx = _PIPE
+    c, s = synthetic_image(3000 + seed, hc, wc), synthetic_image(4000 + seed, hs, ws)
+    need = (1 << (levels[0] - 1)) + 1                     # the deepest feature map must be >= 2x2 (reflect pad)
+    if min(hc, wc, hs, ws) < need:
+        with pytest.raises(_lib.WCTHipError, match='too small for relu%d_1' % levels[0]):
+            ctx.stylize(c, s, targets, alpha=alpha, wct_mode=mode, adain=adain)
+        return
+    got = ctx.stylize(c, s, targets, alpha=alpha, wct_mode=mode, adain=adain)
+    x, s01 = np.float32(c / 255.), np.float32(s / 255.)
+    for i, relu in enumerate(targets):
+        if i > 0:
+            x = np.clip(x, 0, 1)
+        fc, fs = ctx.encode(x, relu), ctx.encode(s01, relu)
+        ch = fc.shape[-1]
+        if adain:
+            t = ctx.adain(fc.reshape(-1, ch), fs.reshape(-1, ch), alpha).reshape(fc.shape)
+        else:
+            if fc.shape[0] * fc.shape[1] < 2 or fs.shape[0] * fs.shape[1] < 2:
+                return                                   # a 1-pixel feature map has no covariance (the reference divides by 0)
+            t = ctx.transform(fc.reshape(-1, ch), fs.reshape(-1, ch), alpha,
+                              _lib.WCT_TF if mode == 'tf' else _lib.WCT_NP).reshape(fc.shape)
+        x = ctx.decode(t, relu)
+    want = np.uint8(np.clip(x, 0, 1) * 255)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), (hc, wc, hs, ws, levels, alpha, mode, adain)

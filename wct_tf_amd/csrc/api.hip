@@ -415,6 +415,20 @@ static void level_dims(int H, int W, int level, int* h, int* w) {
   *h = H; *w = W;
 }
 
+// every 3x3 conv reflect-pads its input by one pixel, which needs a map of at least 2x2 (tf.pad REFLECT refuses a
+// padding >= the dimension just the same): the feature map of the deepest level must still be 2x2
+static int check_min_size(const char* what, int H, int W, int level) {
+  int h, w;
+  level_dims(H, W, level, &h, &w);
+  if (h < 2 || w < 2) {
+    wct_set_error("%s %dx%d is too small for relu%d_1: its %dx%d feature map cannot be reflect-padded (need >= %dx%d pixels)",
+                  what, H, W, level, h, w, (1 << (level - 1)) + 1, (1 << (level - 1)) + 1);
+    return WCT_ERR_ARG;
+  }
+  return WCT_OK;
+}
+
+
 static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16, float* y32,
                     int B, int H, int W, int upsample, int relu, int pool = 0) {
   ConvArgs a;
@@ -656,6 +670,7 @@ extern "C" int wct_maxpool(wct_ctx* c, const float* x, int H, int W, int C, floa
 extern "C" int wct_encode(wct_ctx* c, const float* img01, int H, int W, int level, float* feat) {
   ARG_CHECK(c && img01 && feat && level >= 1 && level <= 5);
   HIP_TRY(hipSetDevice(c->device));
+  TRY(check_min_size("image", H, W, level));
   int h, w;
   level_dims(H, W, level, &h, &w);
   void* dimg;
@@ -728,6 +743,7 @@ extern "C" int wct_output_size(int Hc, int Wc, const int* levels, int n_levels, 
   int H = Hc, W = Wc;
   for (int i = 0; i < n_levels; ++i) {
     ARG_CHECK(levels[i] >= 1 && levels[i] <= 5);
+    TRY(check_min_size("content", H, W, levels[i]));
     int h, w;
     level_dims(H, W, levels[i], &h, &w);
     H = h << (levels[i] - 1); W = w << (levels[i] - 1);     // ceil pooling then x2 upsampling
@@ -749,6 +765,7 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
   }
   int Ho, Wo;
   TRY(wct_output_size(Hc, Wc, levels, n_levels, &Ho, &Wo));
+  TRY(check_min_size("style", Hs, Ws, deepest));
 
   // WCT_FLAG_STYLE_SHARED: `style` is ONE image for all B pairs (a video with a fixed style); its encoder pass,
   // statistics and eigensystems are computed once per call instead of once per pair
