@@ -101,3 +101,34 @@ def test_crc32c_known_answers():
     assert tf_ckpt.crc32c(b'\xff' * 32) == 0x62A8AB43
     assert tf_ckpt.crc32c(bytes(range(32))) == 0x46DD794E
     assert tf_ckpt.crc32c(b'123456789') == 0xE3069283
+
+
+def test_convert_tool_reads_both_reference_formats(tmp_path):
+    """wct_tf_amd.convert: Torch7 encoder + TF decoder checkpoints -> the .npz container, which loads back equal."""
+    from conftest import GOLDEN
+    from wct_tf_amd.convert import main
+    from wct_tf_amd.weights import load_weights
+    rng = np.random.default_rng(3)
+    t, want = decoder_variables('relu1_1', rng)
+    d = tmp_path / 'ck'
+    d.mkdir()
+    write_bundle(str(d / 'model.ckpt-7'), t, block_size=200)
+    write_checkpoint_state(str(d), 'model.ckpt-7')
+    out = str(tmp_path / 'all.npz')
+    main(['--vgg-path', os.path.join(GOLDEN, 'tiny_vgg.t7'), '--checkpoints', str(d), '--relu-targets', 'relu1_1', '--out', out])
+    w = load_weights(out)
+    assert 'conv1_1' in w['encoder'] and 'preprocess' in w['encoder']
+    for (a, b), (a0, b0) in zip(w['decoder']['relu1_1'], want):
+        assert np.array_equal(a, a0) and np.array_equal(b, b0)
+
+
+def test_stylize_cli_rank_shard():
+    from wct_tf_amd.stylize import rank_shard
+    files = ['f%02d' % i for i in range(10)]
+    assert rank_shard(files, {}) == (files, None)
+    seen = []
+    for r in range(4):
+        shard, dev = rank_shard(files, {'WORLD_SIZE': '4', 'RANK': str(r), 'LOCAL_RANK': str(r)})
+        assert dev == '/gpu:%d' % r
+        seen += shard
+    assert seen == files

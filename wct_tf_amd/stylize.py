@@ -44,6 +44,19 @@ def build_parser():
     return parser
 
 
+def rank_shard(items, environ=None):
+    """One process per GPU (`torchrun --nproc-per-node N -m wct_tf_amd.stylize ...`): rank r of WORLD_SIZE takes a
+    contiguous shard of the content files and writes its own outputs -- independent pairs, no collective.
+    Returns (shard, device or None): the device string follows LOCAL_RANK when the launcher set it."""
+    env = os.environ if environ is None else environ
+    world, rank = int(env.get('WORLD_SIZE', '1')), int(env.get('RANK', '0'))
+    if world <= 1:
+        return list(items), None
+    from .dist import shard_range
+    lo, hi = shard_range(len(items), world, rank)
+    return list(items)[lo:hi], '/gpu:%d' % int(env.get('LOCAL_RANK', str(rank)))
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     start = time.time()
@@ -52,11 +65,13 @@ def main(argv=None):
     if args.synthetic_weights is not None:
         from .weights import synthetic_weights
         weights = synthetic_weights(args.synthetic_weights, relu_targets=args.relu_targets)
+    _, rank_device = rank_shard([])
     wct_model = WCT(checkpoints=args.checkpoints, relu_targets=args.relu_targets, vgg_path=args.vgg_path,
-                    device=args.device, ss_patch_size=args.ss_patch_size, ss_stride=args.ss_stride,
+                    device=rank_device or args.device, ss_patch_size=args.ss_patch_size, ss_stride=args.ss_stride,
                     weights=weights, wct_mode=args.wct_mode)
 
     content_files = get_files(args.content_path) if os.path.isdir(args.content_path) else [args.content_path]
+    content_files, _ = rank_shard(sorted(content_files))
     if os.path.isdir(args.style_path):
         style_files = get_files(args.style_path)
         if args.random > 0:
