@@ -333,27 +333,45 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
 // instruction writes 1 KiB of contiguous memory.
 // k = ky*9 + kx*3 + c: a patch row [px][3] holds the 9 values of a ky contiguously.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int tiles_x) {
-  // 16x16 pixel tile x 64 channels per block; wave w owns pixel rows 4w..4w+3 (two 2x16 MFMA pixel tiles)
-  __shared__ float patch[18 * 18 * 3 + 4];     // [972] stays 0: the target of the padded k = 27..31
+__global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int strips_x) {
+  // One block walks a strip of CF_TILES horizontally adjacent 16x16 pixel tiles (x 64 channels); wave w owns pixel
+  // rows 4w..4w+3 of a tile (two 2x16 MFMA pixel tiles).  The next tile's 18x18x3 halo patch is fetched into
+  // registers while the current one is computed, and the per-block set-up (weight fragments, bias, fragment
+  // addresses) is paid once per strip.
+  constexpr int CF_TILES = 4, PATCH_N = 18 * 18 * 3, PER = (PATCH_N + 255) / 256;
+  __shared__ float patch[PATCH_N + 4];         // [972] stays 0: the target of the padded k = 27..31
   __shared__ __attribute__((aligned(16))) unsigned char tr[4][32 * 256];   // per wave: 32 pixels x 64 ch fp32
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int sx = blockIdx.x % strips_x, ty = blockIdx.x / strips_x;
   const int b = blockIdx.y;
-  const int y0 = ty * 16, x0 = tx * 16;
+  const int y0 = ty * 16;
   const float* xb = p.x + (size_t)b * p.H * p.W * 3;
-  for (int i = tid; i < 18 * 18 * 3 + 4; i += 256) {
-    float v = 0.f;
-    if (i < 18 * 18 * 3) {
-      int c = i % 3, pix = i / 3;
-      int py = pix / 18, px = pix - py * 18;
-      int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
-      v = xb[((size_t)iy * p.W + ix) * 3 + c];
-      if (p.clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
-    }
-    patch[i] = v;
+  // this thread's patch elements: (row offset, column in the patch, channel) never change along the strip
+  int e_row[PER], e_px[PER], e_c[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + i * 256;
+    const int pix = e < PATCH_N ? e / 3 : 0;
+    e_c[i] = e < PATCH_N ? e - pix * 3 : 0;
+    const int py = pix / 18;
+    e_px[i] = pix - py * 18;
+    e_row[i] = reflect_idx(y0 - 1 + py, p.H) * p.W;
   }
+  float pre[PER];
+  auto fetch = [&](int x0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      float v = xb[((size_t)e_row[i] + reflect_idx(x0 - 1 + e_px[i], p.W)) * 3 + e_c[i]];
+      pre[i] = p.clamp01 ? fminf(fmaxf(v, 0.f), 1.f) : v;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) if (tid + i * 256 < PATCH_N) patch[tid + i * 256] = pre[i];
+  };
+  if (tid < 4) patch[PATCH_N + tid] = 0.f;
+  fetch(sx * CF_TILES * 16);
   // weight fragments [cout tile][k-step][hi/lo][lane][8]: 8 coalesced 1-KiB loads, register-resident
   half8 wh[2][2], wl[2][2];
 #pragma unroll
@@ -379,9 +397,15 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int ti
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) bias[nt][rq] = *reinterpret_cast<const f32x4*>(p.bias + nt * 32 + 8 * rq + 4 * kgrp);
+  park();
   __syncthreads();
   const unsigned char* pb = reinterpret_cast<const unsigned char*>(patch);
   unsigned char* const wt = tr[wave];
+  for (int tile = 0; tile < CF_TILES; ++tile) {
+  const int x0 = (sx * CF_TILES + tile) * 16;
+  if (x0 >= p.W) break;                        // uniform: the strip runs past the image
+  const bool next = tile + 1 < CF_TILES && x0 + 16 < p.W;
+  if (next) fetch(x0 + 16);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     f32x16 acc[2];
@@ -449,12 +473,18 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int ti
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();           // the region is rewritten by the next pixel tile
   }
+  if (next) {                                  // swap in the next tile's patch once every wave has read this one
+    __syncthreads();
+    park();
+    __syncthreads();
+  }
+  }
 }
 
 int launch_conv_first(const ConvFirstArgs& a, hipStream_t s) {
   ARG_CHECK(a.H > 1 && a.W > 1 && a.B > 0);
-  const int tiles_x = cdiv(a.W, 16), tiles_y = cdiv(a.H, 16);
-  hipLaunchKernelGGL(conv_first_kernel, dim3(tiles_x * tiles_y, a.B), dim3(256), 0, s, a, tiles_x);
+  const int strips_x = cdiv(a.W, 64), tiles_y = cdiv(a.H, 16);
+  hipLaunchKernelGGL(conv_first_kernel, dim3(strips_x * tiles_y, a.B), dim3(256), 0, s, a, strips_x);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
