@@ -148,6 +148,13 @@ int wct_train_step(wct_ctx* ctx, int level, const float* images, int B, int H, i
 int wct_get_decoder_layer(wct_ctx* ctx, int level, int layer, float* w_hwio, float* bias,
                           float* grad_w, float* grad_b);
 
+/* Data-parallel training (one process per GPU): every rank runs wct_train_step(lr = 0) on its own shard of the
+ * batch, the ranks average the gradient buffer below with ONE all-reduce (RCCL), then every rank applies the same
+ * Adam step.  *grad_dev: one contiguous device buffer of *count floats with the gradients of all layers (the
+ * layout is private and identical on every rank).  train_step(lr=0) + train_apply(lr) == train_step(lr), bit for bit. */
+int wct_train_grad_buffer(wct_ctx* ctx, int level, float** grad_dev, size_t* count);
+int wct_train_apply(wct_ctx* ctx, int level, float lr, float beta1, float beta2, float eps, int step);
+
 /* ---- device memory helpers (thin wrappers so callers need no HIP binding) ----------- */
 int wct_dev_alloc(wct_ctx* ctx, size_t bytes, void** out);
 int wct_dev_free(wct_ctx* ctx, void* p);

@@ -144,3 +144,45 @@ def test_train_cli_end_to_end(tmp_path):
     save_weights(vgg, {'encoder': weights['encoder'], 'decoder': {}})
     out = WCT(checkpoints=[ck], relu_targets=['relu2_1'], vgg_path=vgg).predict(synthetic_image(1, 32, 32), synthetic_image(2, 32, 32), 0.8)
     assert out.shape == (32, 32, 3) and out.dtype == np.uint8
+
+
+def test_split_step_equals_fused_step_and_rccl_allreduce_on_the_gradient_buffer():
+    """The data-parallel building blocks on one GPU: train_step(lr=0) + train_apply(lr) equals train_step(lr) bit
+    for bit; the library's contiguous gradient buffer can be wrapped by torch without a copy and all-reduced over
+    RCCL (world size 1 here: the N>1 launch is `torchrun -m wct_tf_amd.train`)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from wct_tf_amd.context import Context
+    from wct_tf_amd.train import _DevArray
+    relu = 'relu2_1'
+    weights = synthetic_weights(42, relu_targets=[relu])
+    x = batch(31, 4, 32, 32)
+    a, b = Context(0), Context(0)
+    for c in (a, b):
+        c.set_weights(weights)
+    for t in range(1, 4):
+        ra = a.train_step(relu, x, step=t, learning_rate=1e-3)
+        rb = b.train_step(relu, x, step=t, learning_rate=0.0)
+        b.train_apply(relu, t, 1e-3)
+        assert ra == rb
+    for (wa, ba), (wb, bb) in zip(a.get_decoder(relu), b.get_decoder(relu)):
+        assert np.array_equal(wa, wb) and np.array_equal(ba, bb)
+    # the gradient buffer as a torch view + one RCCL all-reduce
+    ptr, count = b.train_grad_buffer(relu)
+    g = torch.as_tensor(_DevArray(ptr, count), device='cuda:0')
+    assert g.numel() == count and g.data_ptr() == ptr
+    before = g.clone()
+    sock = socket.socket(); sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]; sock.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(g, before)
+    gw0 = b.get_decoder(relu, grads=True)[0][0]
+    assert np.array_equal(gw0.ravel(), before[:gw0.size].cpu().numpy())      # layer 0's kernel gradient opens the buffer
+    a.close(); b.close()

@@ -46,6 +46,8 @@ SIGNATURES = [
     ('wct_train_step', C.c_int, [_P, C.c_int, _F, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _F]),
     ('wct_get_decoder_layer', C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F]),
+    ('wct_train_grad_buffer', C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ('wct_train_apply', C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int]),
     ('wct_dev_alloc', C.c_int, [_P, C.c_size_t, _PP]),
     ('wct_dev_free', C.c_int, [_P, _P]),
     ('wct_h2d', C.c_int, [_P, _P, _P, C.c_size_t]),

@@ -271,6 +271,19 @@ class Context(object):
                                       float(beta1), float(beta2), float(epsilon), int(step), out))
         return {'feature_loss': out[0], 'pixel_loss': out[1], 'tv_loss': out[2], 'total_loss': out[3]}
 
+    def train_grad_buffer(self, relu_target):
+        """(device pointer, float count) of the decoder's contiguous gradient buffer (data-parallel all-reduce)."""
+        level = _levels([relu_target])[0]
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self.lib.wct_train_grad_buffer(self.h, level, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def train_apply(self, relu_target, step, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        """Adam from the gradients currently in the gradient buffer (after train_step(learning_rate=0) and an
+        all-reduce): the second half of a data-parallel step."""
+        level = _levels([relu_target])[0]
+        check(self.lib.wct_train_apply(self.h, level, float(learning_rate), float(beta1), float(beta2), float(epsilon), int(step)))
+
     def get_decoder(self, relu_target, grads=False):
         """[(w HWIO fp32, b)] of the decoder as it is now on the device (after training steps); with grads=True
         the gradients of the last train_step instead."""

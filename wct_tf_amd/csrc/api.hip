@@ -48,6 +48,8 @@ struct Decoder {
   // per conv of the plan (the output conv last)
   std::vector<float*> w32, b32, mw, vw, mb, vb, gw, gb;
   std::vector<int> cin, cout;
+  float* grad_arena = nullptr;     // gw / gb point into ONE contiguous buffer: a single all-reduce covers a decoder
+  size_t grad_count = 0;
 };
 
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
@@ -159,8 +161,9 @@ static void free_layer(ConvLayer& l) {
 }
 static void free_decoder(Decoder& d) {
   for (auto& l : d.convs) free_layer(l);
-  for (auto* v : {&d.w32, &d.b32, &d.mw, &d.vw, &d.mb, &d.vb, &d.gw, &d.gb})
+  for (auto* v : {&d.w32, &d.b32, &d.mw, &d.vw, &d.mb, &d.vb})
     for (float* p : *v) if (p) hipFree(p);
+  if (d.grad_arena) hipFree(d.grad_arena);
   if (d.last_w) hipFree(d.last_w);
   if (d.last_b) hipFree(d.last_b);
   d = Decoder();
@@ -862,6 +865,52 @@ struct EncStep { int idx; int h, w; half_t* out; half_t* pooled; int ph, pw; }; 
 struct DecStep { int conv; int up; int h, w; const half_t* in; half_t* out; };       // (h, w) = conv output dims
 }  // namespace
 
+// Adam moments (zero) and the gradient arena of a decoder, allocated on first use.  Gradients of all layers live in
+// one contiguous buffer ([w0][b0][w1][b1]..., every piece 64-float aligned) so that data-parallel training needs a
+// single all-reduce per step (wct_train_grad_buffer).
+static int ensure_train_state(wct_ctx* c, Decoder& d) {
+  if (!d.mw.empty()) return WCT_OK;
+  const int nconv = (int)d.w32.size();
+  size_t total = 0;
+  auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+  for (int i = 0; i < nconv; ++i) total += pad((size_t)9 * d.cin[i] * d.cout[i]) + pad((size_t)d.cout[i]);
+  HIP_TRY(hipMalloc((void**)&d.grad_arena, total * sizeof(float)));
+  HIP_TRY(hipMemsetAsync(d.grad_arena, 0, total * sizeof(float), c->stream));
+  d.grad_count = total;
+  size_t off = 0;
+  for (int i = 0; i < nconv; ++i) {
+    const size_t nw = (size_t)9 * d.cin[i] * d.cout[i], nb = (size_t)d.cout[i];
+    float* p[4] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t bytes[4] = {nw * 4, nw * 4, nb * 4, nb * 4};
+    for (int k = 0; k < 4; ++k) { HIP_TRY(hipMalloc((void**)&p[k], bytes[k])); HIP_TRY(hipMemsetAsync(p[k], 0, bytes[k], c->stream)); }
+    d.mw.push_back(p[0]); d.vw.push_back(p[1]); d.mb.push_back(p[2]); d.vb.push_back(p[3]);
+    d.gw.push_back(d.grad_arena + off); off += pad(nw);
+    d.gb.push_back(d.grad_arena + off); off += pad(nb);
+  }
+  return WCT_OK;
+}
+
+// Adam on every conv of the decoder from the gradients currently in the arena, then refresh the fp16 forward weights
+static int apply_adam(wct_ctx* c, Decoder& d, float lr, float beta1, float beta2, float eps, int step) {
+  hipStream_t s = c->stream;
+  const float lr_t = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));
+  int ci = 0;
+  for (int i = 0; i < (int)d.w32.size(); ++i) {
+    const size_t nw = (size_t)9 * d.cin[i] * d.cout[i];
+    TRY(launch_adam(d.w32[i], d.mw[i], d.vw[i], d.gw[i], nw, lr_t, beta1, beta2, eps, s));
+    TRY(launch_adam(d.b32[i], d.mb[i], d.vb[i], d.gb[i], (size_t)d.cout[i], lr_t, beta1, beta2, eps, s));
+    if (d.cout[i] == 3) {
+      TRY(launch_pack_last_frag(d.w32[i], d.last_w, s));
+      HIP_TRY(hipMemcpyAsync(d.last_b, d.b32[i], 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+      ConvLayer& l = d.convs[ci++];
+      TRY(launch_pack_conv_frag(d.w32[i], l.w, l.cin, l.cout, s));
+      HIP_TRY(hipMemcpyAsync(l.b, d.b32[i], (size_t)l.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  return WCT_OK;
+}
+
 // images: host fp32 [B][H][W][3] in [0,1] (train.py:72-83).  losses_out[4] = feature, pixel, tv, total (host).
 // step = 1-based optimiser step (Adam bias correction); lr is the already decayed learning rate (model.py:17-19).
 extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B, int H, int W,
@@ -884,15 +933,7 @@ extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B,
   for (int i = 0; i < 12 && level > 1; ++i) if (seq_tap[i] == level) tap_idx = i;
 
   // optimiser state, allocated on first use
-  if (d.mw.empty()) {
-    for (int i = 0; i < nconv; ++i) {
-      const size_t nw = (size_t)9 * d.cin[i] * d.cout[i];
-      float* p[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-      const size_t bytes[6] = {nw * 4, nw * 4, (size_t)d.cout[i] * 4, (size_t)d.cout[i] * 4, nw * 4, (size_t)d.cout[i] * 4};
-      for (int k = 0; k < 6; ++k) { HIP_TRY(hipMalloc((void**)&p[k], bytes[k])); HIP_TRY(hipMemsetAsync(p[k], 0, bytes[k], s)); }
-      d.mw.push_back(p[0]); d.vw.push_back(p[1]); d.mb.push_back(p[2]); d.vb.push_back(p[3]); d.gw.push_back(p[4]); d.gb.push_back(p[5]);
-    }
-  }
+  TRY(ensure_train_state(c, d));
 
   // ---- carve the workspace (first pass sizes, second pass pointers)
   std::vector<EncStep> enc_steps;
@@ -1048,23 +1089,7 @@ extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B,
   }
 
   // ---- Adam (model.py:199: beta1 0.9, beta2 0.999 in the reference), then refresh the fp16 forward weights
-  const float lr_t = lr * sqrtf(1.f - powf(beta2, (float)step)) / (1.f - powf(beta1, (float)step));
-  if (lr != 0.f) {
-    int ci = 0;
-    for (int i = 0; i < nconv; ++i) {
-      const size_t nw = (size_t)9 * d.cin[i] * d.cout[i];
-      TRY(launch_adam(d.w32[i], d.mw[i], d.vw[i], d.gw[i], nw, lr_t, beta1, beta2, eps, s));
-      TRY(launch_adam(d.b32[i], d.mb[i], d.vb[i], d.gb[i], (size_t)d.cout[i], lr_t, beta1, beta2, eps, s));
-      if (d.cout[i] == 3) {
-        TRY(launch_pack_last_frag(d.w32[i], d.last_w, s));
-        HIP_TRY(hipMemcpyAsync(d.last_b, d.b32[i], 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
-      } else {
-        ConvLayer& l = d.convs[ci++];
-        TRY(launch_pack_conv_frag(d.w32[i], l.w, l.cin, l.cout, s));
-        HIP_TRY(hipMemcpyAsync(l.b, d.b32[i], (size_t)l.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
-      }
-    }
-  }
+  if (lr != 0.f) TRY(apply_adam(c, d, lr, beta1, beta2, eps, step));
   float hl[4];
   HIP_TRY(hipMemcpyAsync(hl, dloss, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -1086,6 +1111,30 @@ extern "C" int wct_get_decoder_layer(wct_ctx* c, int level, int layer, float* w_
   if (bias) HIP_TRY(hipMemcpyAsync(bias, d.b32[layer], nb, hipMemcpyDeviceToHost, c->stream));
   if (grad_w) HIP_TRY(hipMemcpyAsync(grad_w, d.gw[layer], nw, hipMemcpyDeviceToHost, c->stream));
   if (grad_b) HIP_TRY(hipMemcpyAsync(grad_b, d.gb[layer], nb, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return WCT_OK;
+}
+
+// Data-parallel training: run wct_train_step with lr = 0 on every rank's shard, all-reduce (average) the gradient
+// buffer this returns over RCCL, then wct_train_apply on every rank.  *grad_dev is ONE contiguous device buffer of
+// *count floats holding the gradients of all layers of the decoder (the layout is private; it is the same on every
+// rank).  The single-process sequence train_step(lr=0) + train_apply(lr) equals train_step(lr) bit for bit.
+extern "C" int wct_train_grad_buffer(wct_ctx* c, int level, float** grad_dev, size_t* count) {
+  ARG_CHECK(c && grad_dev && count && level >= 1 && level <= 5);
+  HIP_TRY(hipSetDevice(c->device));
+  Decoder& d = c->dec[level];
+  if (!d.loaded) { wct_set_error("decoder weights for relu%d_1 not set (wct_set_decoder)", level); return WCT_ERR_STATE; }
+  TRY(ensure_train_state(c, d));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *grad_dev = d.grad_arena; *count = d.grad_count;
+  return WCT_OK;
+}
+extern "C" int wct_train_apply(wct_ctx* c, int level, float lr, float beta1, float beta2, float eps, int step) {
+  ARG_CHECK(c && level >= 1 && level <= 5 && step >= 1);
+  HIP_TRY(hipSetDevice(c->device));
+  Decoder& d = c->dec[level];
+  if (!d.loaded || d.mw.empty()) { wct_set_error("no gradients for relu%d_1: run wct_train_step first", level); return WCT_ERR_STATE; }
+  TRY(apply_adam(c, d, lr, beta1, beta2, eps, step));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return WCT_OK;
 }

@@ -6,6 +6,12 @@ kernels, losses (feature MSE, pixel MSE, total variation), fp32 backward, Adam, 
 weights.  The host only produces batches (random 256x256 crops of images resized to 512, train.py:60-87) on a
 loader thread, logs, and writes checkpoints.
 
+Multi-GPU (`torchrun --nproc-per-node N --master-addr 127.0.0.1 -m wct_tf_amd.train ...`): data parallel, one
+process per GPU, `--batch-size` images PER GPU.  Every rank computes the gradients of its own batch
+(`wct_train_step` with lr = 0), the ranks average the decoder's gradient buffer -- ONE contiguous device buffer, ONE
+all-reduce over RCCL per step -- and every rank applies the same Adam step (`wct_train_apply`), so the replicas stay
+bit-identical.  Rank 0 logs (losses averaged over ranks) and writes the checkpoints.
+
 Differences from the reference, forced by the environment: no TensorFlow, so no summaries / FIFOQueue / Saver.
 Checkpoints are `decoder_<relu>.npz` files in --checkpoint (the layout `WCT(checkpoints=[dir])` reads back) plus a
 `train_state.json` with the step counter; `--max-to-keep` numbered snapshots are rotated like the Saver does.
@@ -131,9 +137,35 @@ def load_latest(directory, relu_target):
     return load_weights(latest)['decoder'][relu_target], step
 
 
+class _DevArray(object):
+    """A device buffer owned by the library, exposed through __cuda_array_interface__ so that torch can wrap it
+    without a copy (torch.as_tensor) and hand it to RCCL."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {'shape': (count,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2}
+
+
+def _dist_setup():
+    """(rank, world, torch.distributed or None).  Under torchrun the device follows LOCAL_RANK."""
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world <= 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    torch.cuda.set_device(local)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=rank, world_size=world)      # RCCL over xGMI
+    return rank, world, dist
+
+
 def train(argv=None):
     args = build_parser().parse_args(argv)
     relu = args.relu_target
+    rank, world, dist = _dist_setup()
+    if dist is not None:
+        args.device = int(os.environ.get('LOCAL_RANK', str(rank)))
     if args.synthetic_weights is not None:
         weights = synthetic_weights(args.synthetic_weights, relu_targets=[relu])
     else:
@@ -155,12 +187,43 @@ def train(argv=None):
     shape = (args.batch_size, args.crop, args.crop, 3)
     if args.synthetic_data is None and not args.content_path:
         raise SystemExit('--content-path (or --synthetic-data N) is required')
-    train_q = _start_loader(batch_gen(args.content_path, shape, args.synthetic_data, seed=1))
+    train_q = _start_loader(batch_gen(args.content_path, shape, args.synthetic_data, seed=1 + 1000 * rank))
     val_folder = args.val_path if args.val_path is not None else args.content_path
-    val_q = _start_loader(batch_gen(val_folder, shape, args.synthetic_data, seed=2))
+    val_q = _start_loader(batch_gen(val_folder, shape, args.synthetic_data, seed=2 + 1000 * rank))
     log_path = args.log_path if args.log_path is not None else os.path.join(args.checkpoint, 'log')
-    os.makedirs(log_path, exist_ok=True)
-    log = open(os.path.join(log_path, 'train_log.jsonl'), 'a')
+    log = None
+    if rank == 0:
+        os.makedirs(log_path, exist_ok=True)
+        log = open(os.path.join(log_path, 'train_log.jsonl'), 'a')
+    grad = [None]
+    if dist is not None:
+        import torch
+
+    def bind_grad():
+        if dist is not None:
+            ptr, count = ctx.train_grad_buffer(relu)
+            grad[0] = torch.as_tensor(_DevArray(ptr, count), device='cuda:%d' % args.device)     # a view, no copy
+    bind_grad()
+
+    def one_step(x, step, lr):
+        """single GPU: one fused call; data parallel: gradients, one all-reduce (average), the same Adam everywhere"""
+        if dist is None or lr == 0.0:
+            res = ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
+                                 pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+        else:
+            res = ctx.train_step(relu, x, step=step, learning_rate=0.0, feature_weight=args.feature_weight,
+                                 pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+            dist.all_reduce(grad[0], op=dist.ReduceOp.SUM)
+            grad[0].div_(world)
+            torch.cuda.synchronize()
+            ctx.train_apply(relu, step, lr)
+        if dist is not None:
+            t = torch.tensor([res['feature_loss'], res['pixel_loss'], res['tv_loss'], res['total_loss']], dtype=torch.float64,
+                             device='cuda:%d' % args.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t = (t / world).tolist()
+            res = {'feature_loss': t[0], 'pixel_loss': t[1], 'tv_loss': t[2], 'total_loss': t[3]}
+        return res
 
     step = step0
     results = None
@@ -170,8 +233,7 @@ def train(argv=None):
         lr = torch_decay(args.learning_rate, step, args.lr_decay)
         step += 1
         try:
-            results = ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
-                                     pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+            results = one_step(x, step, lr)
             if not np.isfinite(results['total_loss']):
                 raise FloatingPointError('non-finite loss at step %d' % step)
         except Exception as e:                     # noqa: BLE001  train.py:168-174: reload the latest checkpoint and go on
@@ -181,20 +243,25 @@ def train(argv=None):
             if restored is None:
                 raise
             ctx.set_decoder(relu, restored)        # fresh optimiser state, as a restored graph would have saved ones
+            bind_grad()                            # the gradient buffer was re-created with the decoder
             step = step_saved
             continue
         rec = dict(results, step=step, lr=lr, time=time.time() - start)
         if iteration % args.summary_iter == 0:          # a validation batch, evaluated without an update
-            val = ctx.train_step(relu, val_q.get(), step=step, learning_rate=0.0, feature_weight=args.feature_weight,
-                                 pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+            val = one_step(val_q.get(), step, 0.0)
             rec['val_total_loss'] = val['total_loss']
-        log.write(json.dumps(rec) + '\n')
-        log.flush()
-        if iteration % args.save_iter == 0:
-            print('Model saved in file: %s' % save_checkpoint(ctx, relu, args.checkpoint, step, args.max_to_keep))
-        print('Step: {}  LR: {:.7f}  Feature: {:.5f}  Pixel: {:.5f}  TV: {:.5f}  Time: {:.5f}'.format(
-            step, lr, results['feature_loss'], results['pixel_loss'], results['tv_loss'], time.time() - start))
-    print('Model saved in file: %s' % save_checkpoint(ctx, relu, args.checkpoint, step, args.max_to_keep))
+        if rank == 0:
+            log.write(json.dumps(rec) + '\n')
+            log.flush()
+            if iteration % args.save_iter == 0:
+                print('Model saved in file: %s' % save_checkpoint(ctx, relu, args.checkpoint, step, args.max_to_keep))
+            print('Step: {}  LR: {:.7f}  Feature: {:.5f}  Pixel: {:.5f}  TV: {:.5f}  Time: {:.5f}'.format(
+                step, lr, results['feature_loss'], results['pixel_loss'], results['tv_loss'], time.time() - start))
+    if rank == 0:
+        print('Model saved in file: %s' % save_checkpoint(ctx, relu, args.checkpoint, step, args.max_to_keep))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     ctx.close()
     return results
 
