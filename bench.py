@@ -106,10 +106,15 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the stylize path has no CPU fallback')
+    # dry-run switches for a box with fewer GPUs than ranks (the control flow of the N > 1 path without RCCL):
+    # WCT_BENCH_BACKEND=gloo stages the exchange through the host, WCT_BENCH_SHARE_GPU=1 wraps ranks onto the GPUs
+    backend = os.environ.get('WCT_BENCH_BACKEND', 'nccl')
+    if os.environ.get('WCT_BENCH_SHARE_GPU'):
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)       # RCCL over xGMI
+        dist.init_process_group(backend, rank=rank, world_size=world)      # 'nccl' = RCCL over xGMI
 
     from wct_tf_amd.context import Context
     from wct_tf_amd.weights import synthetic_weights, synthetic_image
@@ -139,7 +144,7 @@ def main():
                               B, LEVELS, args.alpha, C.c_void_p(d_out.data_ptr()), shared_style=args.shared_style)
         if world > 1:
             ctx.sync()                                                     # library stream -> torch stream hand-off
-            frames = gather_frames(d_out, world, rank)
+            frames = gather_frames(d_out if backend == 'nccl' else d_out.cpu(), world, rank)
             torch.cuda.synchronize()                                       # RCCL must be done with d_out before the
             return frames                                                  # next step overwrites it on the library stream
         return None
@@ -163,7 +168,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.prof_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
