@@ -153,10 +153,14 @@ def _dist_setup():
     import torch
     import torch.distributed as dist
     local = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if os.environ.get('WCT_TRAIN_SHARE_GPU'):      # dry run on a box with fewer GPUs than ranks
+        local %= torch.cuda.device_count()
+        os.environ['LOCAL_RANK'] = str(local)
     torch.cuda.set_device(local)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if not dist.is_initialized():
-        dist.init_process_group('nccl', rank=rank, world_size=world)      # RCCL over xGMI
+        # 'nccl' = RCCL over xGMI; WCT_TRAIN_BACKEND=gloo stages the all-reduce through the host (dry run)
+        dist.init_process_group(os.environ.get('WCT_TRAIN_BACKEND', 'nccl'), rank=rank, world_size=world)
     return rank, world, dist
 
 
@@ -213,13 +217,18 @@ def train(argv=None):
         else:
             res = ctx.train_step(relu, x, step=step, learning_rate=0.0, feature_weight=args.feature_weight,
                                  pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
-            dist.all_reduce(grad[0], op=dist.ReduceOp.SUM)
-            grad[0].div_(world)
+            if dist.get_backend() == 'nccl':
+                dist.all_reduce(grad[0], op=dist.ReduceOp.SUM)
+                grad[0].div_(world)
+            else:                                   # host-staged dry run
+                host = grad[0].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                grad[0].copy_(host / world)
             torch.cuda.synchronize()
             ctx.train_apply(relu, step, lr)
         if dist is not None:
             t = torch.tensor([res['feature_loss'], res['pixel_loss'], res['tv_loss'], res['total_loss']], dtype=torch.float64,
-                             device='cuda:%d' % args.device)
+                             device='cuda:%d' % args.device if dist.get_backend() == 'nccl' else 'cpu')
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t = (t / world).tolist()
             res = {'feature_loss': t[0], 'pixel_loss': t[1], 'tv_loss': t[2], 'total_loss': t[3]}
@@ -260,6 +269,9 @@ def train(argv=None):
     if rank == 0:
         print('Model saved in file: %s' % save_checkpoint(ctx, relu, args.checkpoint, step, args.max_to_keep))
     if dist is not None:
+        import hashlib
+        digest = hashlib.sha1(b''.join(w.tobytes() + b.tobytes() for w, b in ctx.get_decoder(relu))).hexdigest()
+        print('rank %d decoder digest %s' % (rank, digest))       # identical on every rank: the replicas never diverge
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
