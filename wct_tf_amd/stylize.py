@@ -1,46 +1,48 @@
-"""`python -m wct_tf_amd.stylize ...`: the reference's stylize.py CLI (stylize.py:14-126) on the MI355X
-path.  Same flags and output naming ({content}_{style}{ext}); `--checkpoints` / `--vgg-path` take .npz
-files written by wct_tf_amd.weights.save_weights (see wct.py), or `--synthetic-weights SEED` stands in
-for the absent pre-trained files."""
-from __future__ import division, print_function
-
+"""`python -m wct_tf_amd.stylize ...`: the command line of the reference's stylize.py (stylize.py:14-126) on the
+MI355X path.  Flag names, defaults and the output naming `{content}_{style}{ext}` are the reference's; `--checkpoints`
+takes TF checkpoint directories or .npz files (see wct.py), `--vgg-path` the .t7 or a .npz, and
+`--synthetic-weights SEED` stands in when neither exists.  Under torchrun each rank takes a shard of the content
+files (rank_shard)."""
 import argparse
 import os
 import time
 
 import numpy as np
 
-from .utils import get_files, get_img, save_img, resize_to, center_crop, _imresize
+from . import utils
 from .wct import WCT
+
+# (flags, keyword arguments) -- the interface of stylize.py:16-37, then the additions of this path
+_FLAGS = [
+    (('--checkpoints',), dict(nargs='+', default=None, help='one decoder checkpoint (directory or .npz) per relu target')),
+    (('--relu-targets',), dict(nargs='+', required=True, help='relu layers to stylize at, in pipeline order')),
+    (('--vgg-path',), dict(default=None, help='encoder weights: vgg_normalised.t7 or .npz')),
+    (('--content-path',), dict(dest='content_path', help='content image, or a folder of them')),
+    (('--style-path',), dict(dest='style_path', help='style image, or a folder of them')),
+    (('--out-path',), dict(dest='out_path', help='folder the results are written to')),
+    (('--keep-colors',), dict(action='store_true', default=False, help='CORAL: give the style the colours of the content first')),
+    (('--device',), dict(default='/gpu:0', help='e.g. /gpu:0')),
+    (('--style-size',), dict(type=int, default=0, help='short side of the style image (0: as is)')),
+    (('--crop-size',), dict(type=int, default=0, help='centre-crop the style image to a square of this side (0: no)')),
+    (('--content-size',), dict(type=int, default=0, help='short side of the content image (0: as is)')),
+    (('--passes',), dict(type=int, default=1, help='feed the result back in this many times')),
+    (('-r', '--random'), dict(type=int, default=0, help='use this many randomly chosen styles of the style folder')),
+    (('--alpha',), dict(type=float, default=1, help='style strength: blend of transformed and content features')),
+    (('--concat',), dict(action='store_true', default=False, help='put the style image to the left of every result')),
+    (('--adain',), dict(action='store_true', default=False, help='AdaIN instead of WCT at every level')),
+    (('--swap5',), dict(action='store_true', default=False, help='style-swap at relu5_1')),
+    (('--ss-alpha',), dict(type=float, default=0.6, help='style-swap blend')),
+    (('--ss-patch-size',), dict(type=int, default=3, help='style-swap patch size')),
+    (('--ss-stride',), dict(type=int, default=1, help='style-swap stride')),
+    (('--synthetic-weights',), dict(type=int, default=None, metavar='SEED', help='seeded synthetic weights instead of files')),
+    (('--wct-mode',), dict(choices=['tf', 'np'], default='tf', help='wct_tf (the graph) or wct_np semantics')),
+]
 
 
 def build_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--checkpoints', nargs='+', type=str, help='List of decoder weight files/dirs', default=None)
-    parser.add_argument('--relu-targets', nargs='+', type=str, help='List of reluX_1 layers, corresponding to --checkpoints', required=True)
-    parser.add_argument('--vgg-path', type=str, help='Path to the encoder weights (.npz)', default=None)
-    parser.add_argument('--content-path', type=str, dest='content_path', help='Content image or folder of images')
-    parser.add_argument('--style-path', type=str, dest='style_path', help='Style image or folder of images')
-    parser.add_argument('--out-path', type=str, dest='out_path', help='Output folder path')
-    parser.add_argument('--keep-colors', action='store_true', help="Preserve the colors of the style image", default=False)
-    parser.add_argument('--device', type=str, help='Device to perform compute on, e.g. /gpu:0', default='/gpu:0')
-    parser.add_argument('--style-size', type=int, help="Resize style image to this size before cropping", default=0)
-    parser.add_argument('--crop-size', type=int, help="Crop square size", default=0)
-    parser.add_argument('--content-size', type=int, help="Resize short side of content image to this", default=0)
-    parser.add_argument('--passes', type=int, help="# of stylization passes per content image", default=1)
-    parser.add_argument('-r', '--random', type=int, help="Choose # of random subset of images from style folder", default=0)
-    parser.add_argument('--alpha', type=float, help="Alpha blend value", default=1)
-    parser.add_argument('--concat', action='store_true', help="Concatenate style image and stylized output", default=False)
-    parser.add_argument('--adain', action='store_true', help="Use AdaIN instead of WCT", default=False)
-    # Style swap args
-    parser.add_argument('--swap5', action='store_true', help="Swap style on layer relu5_1", default=False)
-    parser.add_argument('--ss-alpha', type=float, help="Style swap alpha blend", default=0.6)
-    parser.add_argument('--ss-patch-size', type=int, help="Style swap patch size", default=3)
-    parser.add_argument('--ss-stride', type=int, help="Style swap stride", default=1)
-    # additions of this path
-    parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED',
-                        help='use seeded synthetic weights instead of --checkpoints/--vgg-path')
-    parser.add_argument('--wct-mode', choices=['tf', 'np'], default='tf', help='wct_tf (graph) or wct_np semantics')
+    parser = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    for names, kw in _FLAGS:
+        parser.add_argument(*names, **kw)
     return parser
 
 
@@ -57,64 +59,66 @@ def rank_shard(items, environ=None):
     return list(items)[lo:hi], '/gpu:%d' % int(env.get('LOCAL_RANK', str(rank)))
 
 
+def _listing(path):
+    return utils.get_files(path) if os.path.isdir(path) else [path]
+
+
+def _stem(path):
+    return os.path.splitext(os.path.basename(path))[0]
+
+
+def load_style(path, args):
+    """style image after --style-size / --crop-size (stylize.py:76-83)"""
+    img = utils.get_img(path)
+    if args.style_size > 0:
+        img = utils.resize_to(img, args.style_size)
+    if args.crop_size > 0:
+        img = utils.center_crop(img, args.crop_size)
+    return img
+
+
+def stylize_pair(model, content, style, args):
+    """one output image: optional CORAL, `--passes` predictions, optional `--concat` (stylize.py:85-110)"""
+    if args.keep_colors:
+        from .ops import preserve_colors_np
+        style = preserve_colors_np(style, content, ctx=model.sess)
+    out = content
+    for _ in range(max(1, args.passes)):
+        out = model.predict(out, style, args.alpha, args.swap5, args.ss_alpha, args.adain)
+    if args.concat:
+        side = out.shape[0]
+        out = np.hstack([utils._imresize(style, (side, side)), out])
+    return out
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    start = time.time()
-
+    t0 = time.time()
     weights = None
     if args.synthetic_weights is not None:
         from .weights import synthetic_weights
         weights = synthetic_weights(args.synthetic_weights, relu_targets=args.relu_targets)
-    _, rank_device = rank_shard([])
-    wct_model = WCT(checkpoints=args.checkpoints, relu_targets=args.relu_targets, vgg_path=args.vgg_path,
-                    device=rank_device or args.device, ss_patch_size=args.ss_patch_size, ss_stride=args.ss_stride,
-                    weights=weights, wct_mode=args.wct_mode)
-
-    content_files = get_files(args.content_path) if os.path.isdir(args.content_path) else [args.content_path]
-    content_files, _ = rank_shard(sorted(content_files))
-    if os.path.isdir(args.style_path):
-        style_files = get_files(args.style_path)
-        if args.random > 0:
-            style_files = np.random.choice(style_files, args.random)
-    else:
-        style_files = [args.style_path]
-
+    contents, device = rank_shard(sorted(_listing(args.content_path)))
+    model = WCT(checkpoints=args.checkpoints, relu_targets=args.relu_targets, vgg_path=args.vgg_path,
+                device=device or args.device, ss_patch_size=args.ss_patch_size, ss_stride=args.ss_stride,
+                weights=weights, wct_mode=args.wct_mode)
+    styles = _listing(args.style_path)
+    if os.path.isdir(args.style_path) and args.random > 0:
+        styles = list(np.random.choice(styles, args.random))
     os.makedirs(args.out_path, exist_ok=True)
-    count = 0
-    for content_fullpath in content_files:
-        content_prefix, content_ext = os.path.splitext(content_fullpath)
-        content_prefix = os.path.basename(content_prefix)
-        content_img = get_img(content_fullpath)
+    written = 0
+    for cpath in contents:
+        content = utils.get_img(cpath)
         if args.content_size > 0:
-            content_img = resize_to(content_img, args.content_size)
-
-        for style_fullpath in style_files:
-            style_prefix, _ = os.path.splitext(style_fullpath)
-            style_prefix = os.path.basename(style_prefix)
-            style_img = get_img(style_fullpath)
-            if args.style_size > 0:
-                style_img = resize_to(style_img, args.style_size)
-            if args.crop_size > 0:
-                style_img = center_crop(style_img, args.crop_size)
-            if args.keep_colors:
-                from .ops import preserve_colors_np
-                style_img = preserve_colors_np(style_img, content_img, ctx=wct_model.sess)
-
-            stylized_rgb = wct_model.predict(content_img, style_img, args.alpha, args.swap5, args.ss_alpha, args.adain)
-            for _ in range(args.passes - 1):
-                stylized_rgb = wct_model.predict(stylized_rgb, style_img, args.alpha, args.swap5, args.ss_alpha, args.adain)
-
-            if args.concat:
-                style_img_resized = _imresize(style_img, (stylized_rgb.shape[0], stylized_rgb.shape[0]))
-                stylized_rgb = np.hstack([style_img_resized, stylized_rgb])
-
-            out_f = os.path.join(args.out_path, '{}_{}{}'.format(content_prefix, style_prefix, content_ext))
-            save_img(out_f, stylized_rgb)
-            count += 1
-            print("{}: Wrote stylized output image to {}".format(count, out_f))
-
-    print("Finished stylizing {} outputs in {}s".format(count, time.time() - start))
-    return count
+            content = utils.resize_to(content, args.content_size)
+        for spath in styles:
+            result = stylize_pair(model, content, load_style(spath, args), args)
+            target = os.path.join(args.out_path, '%s_%s%s' % (_stem(cpath), _stem(spath), os.path.splitext(cpath)[1]))
+            utils.save_img(target, result)
+            written += 1
+            print('%d: wrote %s' % (written, target))
+    print('%d outputs in %.1f s' % (written, time.time() - t0))
+    return written
 
 
 if __name__ == '__main__':

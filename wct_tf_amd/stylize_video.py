@@ -30,36 +30,40 @@ from .wct import WCT
 TMP_DIR = '_____fns_frames_%s/' % random.randint(0, 99999)
 
 
+# (flags, keyword arguments): the interface of stylize_video.py:18-41, then the additions of this path
+_FLAGS = [
+    (('--checkpoints',), dict(nargs='+', default=None, help='one decoder checkpoint (directory or .npz) per relu target')),
+    (('--relu-targets',), dict(nargs='+', required=True, help='relu layers to stylize at, in pipeline order')),
+    (('--vgg-path',), dict(default=None, help='encoder weights: vgg_normalised.t7 or .npz')),
+    (('--in-path',), dict(required=True, help='a video file (needs ffmpeg on PATH) or a directory of frames')),
+    (('--out-path',), dict(required=True, help='folder the results are written to')),
+    (('--style-path',), dict(required=True, help='style image, or a folder of them (one output per style)')),
+    (('--tmp-dir',), dict(dest='tmp_dir', default=TMP_DIR, help='scratch folder for extracted / stylized frames')),
+    (('--keep-tmp',), dict(action='store_true', default=False, help='leave the scratch folder in place')),
+    (('--keep-colors',), dict(action='store_true', default=False, help='CORAL: give the style the colours of each frame first')),
+    (('--style-size',), dict(type=int, default=0, help='short side of the style image (0: as is)')),
+    (('--crop-size',), dict(type=int, default=0, help='centre-crop the style image to a square of this side (0: no)')),
+    (('--content-size',), dict(type=int, default=0, help='short side of every frame (0: as is)')),
+    (('--passes',), dict(type=int, default=1, help='feed the result back in this many times')),
+    (('--device',), dict(default='/gpu:0', help='e.g. /gpu:0')),
+    (('--alpha',), dict(type=float, default=1, help='style strength')),
+    (('--concat',), dict(action='store_true', default=False, help='put the style image to the left of every frame')),
+    (('--swap5',), dict(action='store_true', default=False, help='style-swap at relu5_1')),
+    (('--ss-alpha',), dict(type=float, default=0.6, help='style-swap blend')),
+    (('--ss-patch-size',), dict(type=int, default=3, help='style-swap patch size')),
+    (('--ss-stride',), dict(type=int, default=1, help='style-swap stride')),
+    (('--adain',), dict(action='store_true', default=False, help='AdaIN instead of WCT at every level')),
+    (('--batch',), dict(type=int, default=16, help='frames per device batch (<= 32)')),
+    (('--fps',), dict(type=int, default=30, help='frame rate of the re-encoded video (reference: 30)')),
+    (('--synthetic-weights',), dict(type=int, default=None, metavar='SEED', help='seeded synthetic weights instead of files')),
+    (('--wct-mode',), dict(choices=['tf', 'np'], default='tf', help='wct_tf (the graph) or wct_np semantics')),
+]
+
+
 def build_parser():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--checkpoints', nargs='+', type=str, help='List of decoder weight files/dirs', default=None)
-    parser.add_argument('--relu-targets', nargs='+', type=str, help='List of reluX_1 layers, corresponding to --checkpoints', required=True)
-    parser.add_argument('--vgg-path', type=str, help='Path to the encoder weights', default=None)
-    parser.add_argument('--in-path', type=str, help='Path to a video file (needs ffmpeg) or a directory of frames', required=True)
-    parser.add_argument('--out-path', type=str, help='Output folder path', required=True)
-    parser.add_argument('--style-path', type=str, help='Path to style image (or a folder of them)', required=True)
-    parser.add_argument('--tmp-dir', type=str, dest='tmp_dir', help='tmp dir for processing', default=TMP_DIR)
-    parser.add_argument('--keep-tmp', action='store_true', help='Don\'t remove stylized image tmp dir after', default=False)
-    parser.add_argument('--keep-colors', action='store_true', help="Preserve the colors of the style image", default=False)
-    parser.add_argument('--style-size', type=int, help="Resize style image to this size before cropping", default=0)
-    parser.add_argument('--crop-size', type=int, help="Crop square size", default=0)
-    parser.add_argument('--content-size', type=int, help="Resize short side of content image to this", default=0)
-    parser.add_argument('--passes', type=int, help="# of stylization passes per content image", default=1)
-    parser.add_argument('--device', type=str, help='Device to perform compute on, e.g. /gpu:0', default='/gpu:0')
-    parser.add_argument('--alpha', type=float, help="Alpha blend value", default=1)
-    parser.add_argument('--concat', action='store_true', help="Concatenate style image and stylized output", default=False)
-    # Style swap args
-    parser.add_argument('--swap5', action='store_true', help="Swap style on layer relu5_1", default=False)
-    parser.add_argument('--ss-alpha', type=float, help="Style swap alpha blend", default=0.6)
-    parser.add_argument('--ss-patch-size', type=int, help="Style swap patch size", default=3)
-    parser.add_argument('--ss-stride', type=int, help="Style swap stride", default=1)
-    # additions of this path
-    parser.add_argument('--adain', action='store_true', help="Use AdaIN instead of WCT", default=False)
-    parser.add_argument('--batch', type=int, default=16, help='frames per device batch (<= 32)')
-    parser.add_argument('--fps', type=int, default=30, help='frame rate of the re-encoded video (reference: 30)')
-    parser.add_argument('--synthetic-weights', type=int, default=None, metavar='SEED',
-                        help='use seeded synthetic weights instead of --checkpoints/--vgg-path')
-    parser.add_argument('--wct-mode', choices=['tf', 'np'], default='tf', help='wct_tf (graph) or wct_np semantics')
+    parser = argparse.ArgumentParser(description=__doc__.split('\n')[0])
+    for names, kw in _FLAGS:
+        parser.add_argument(*names, **kw)
     return parser
 
 
