@@ -995,7 +995,7 @@ extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B,
     g0 = ar.take<float>(gmax); g1 = ar.take<float>(gmax);
     col = ar.take<float>(colmax); gp = ar.take<float>(gpmax);
     partial = ar.take<float>(partmax); wt = ar.take<float>(wtmax);
-    lpart = ar.take<double>(1024); dloss = ar.take<float>(4);
+    lpart = ar.take<double>(1024); dloss = ar.take<float>(16);      // 4 losses + scratch of the backward GEMMs
     total = ar.off;
   }
 
@@ -1043,7 +1043,8 @@ extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B,
     for (int k = (int)enc_steps.size() - 1; k >= 0; --k) {
       const EncStep& es = enc_steps[k];
       const int cin = ENC_CIN[es.idx], cout = ENC_COUT[es.idx];
-      TRY(launch_conv_dgrad(g, c->enc_wt[es.idx], B, es.h, es.w, cin, cout, col, gp, gother, s));   // w.r.t. the conv input
+      TRY(launch_pow2_scale(g, (size_t)B * es.h * es.w * cout, dloss + 8, s));
+      TRY(launch_conv_dgrad(g, c->enc_wt[es.idx], B, es.h, es.w, cin, cout, col, gp, gother, dloss + 8, s));   // w.r.t. the conv input
       std::swap(g, gother);
       if (k > 0) {
         const EncStep& pv = enc_steps[k - 1];
@@ -1076,10 +1077,11 @@ extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B,
       std::swap(g, gother);
       cpad = 4;
     }
-    TRY(launch_conv_wgrad(ds.in, ds.up, g, cpad, B, ds.h, ds.w, cin, cout, col, partial, conv_wgrad_splits(B, ds.h, ds.w), d.gw[ds.conv], s));
+    TRY(launch_pow2_scale(g, px * cpad, dloss + 8, s));                  // one scale per gradient tensor, both GEMMs use it
+    TRY(launch_conv_wgrad(ds.in, ds.up, g, cpad, B, ds.h, ds.w, cin, cout, col, partial, conv_wgrad_splits(B, ds.h, ds.w), d.gw[ds.conv], dloss + 8, s));
     if (k > 0) {
       TRY(launch_transpose_w(d.w32[ds.conv], wt, cin, cout, cpad, s));
-      TRY(launch_conv_dgrad(g, wt, B, ds.h, ds.w, cin, cpad, col, gp, gother, s));
+      TRY(launch_conv_dgrad(g, wt, B, ds.h, ds.w, cin, cpad, col, gp, gother, dloss + 8, s));
       std::swap(g, gother);
       if (ds.up) {
         TRY(launch_upsample_adjoint(g, gother, B, ds.h / 2, ds.w / 2, cin, s));

@@ -149,10 +149,11 @@ int launch_pack_last_frag(const float* w, half_t* frag, hipStream_t s);
 int launch_transpose_w(const float* w, float* wt, int cin, int cout, int cout_pad, hipStream_t s);
 int launch_pad3to4(const float* x, float* y, size_t n, hipStream_t s);
 int launch_conv_dgrad(const float* g, const float* wt, int B, int H, int W, int cin, int cout,
-                      float* col, float* gp, float* gin, hipStream_t s);
+                      float* col, float* gp, float* gin, void* scratch, hipStream_t s);
 int launch_conv_wgrad(const half_t* x16, int upsample, const float* g, int ldg, int B, int H, int W, int cin, int cout,
-                      float* col, float* partial, int nsplit, float* dw, hipStream_t s);
+                      float* col, float* partial, int nsplit, float* dw, void* scratch, hipStream_t s);
 int conv_wgrad_splits(int B, int H, int W);
+int launch_pow2_scale(const float* x, size_t n, void* scratch, hipStream_t s);   // scratch[1] = 2^k with max|x| 2^k in [8192,16384)
 int launch_conv_first_dgrad(const float* g, const float* wf, float* gp, int B, int H, int W, hipStream_t s);
 
 // ---- coral.hip ------------------------------------------------------------

@@ -5,7 +5,7 @@
 //   dgrad  dXp[p'][ci] = sum_{tap,co} dY[p' - tap][co] W[tap][ci][co]     im2col("full", zero pad) x GEMM
 //          followed by the adjoint of the 1-px REFLECT pad (border rows/columns fold back inside)
 //   wgrad  dW[tap][ci][co] = sum_p Xp[p + tap][ci] dY[p][co]              im2col(reflect pad) ^T x GEMM, split-K
-// both on the fp32 MFMA GEMM of wct.hip (gemm_f32_kernel).  ReLU masks come from the saved activations, the
+// both on a split-operand fp16-MFMA GEMM (gemm_f16x2_kernel below).  ReLU masks come from the saved activations, the
 // x2 nearest upsample and the ceil-mode 2x2 max-pool have their adjoints here, as have the three losses of
 // model.py:181-194 (feature MSE, pixel MSE, total variation) and Adam (tf.train.AdamOptimizer, model.py:199).
 // Every reduction is two-stage with a fixed order: a training step is bit-reproducible.
@@ -242,13 +242,25 @@ int launch_tv(const float* x, int B, int H, int W, int C, float weight, float* g
 // bias gradient: column sums of g [rows][C] in two fixed-order stages; split-K reduction of wgrad partials
 // ---------------------------------------------------------------------------
 __global__ void colsum_rows_kernel(const float* g, size_t rows, int C, int nslab, float* partial) {
+  // 256 threads = rg row groups x min(C, 256) channels; the row groups of a slab are added in a fixed order
+  __shared__ float red[256];
   const int slab = blockIdx.x;
   const size_t per = (rows + nslab - 1) / nslab;
   const size_t r0 = slab * per, r1 = r0 + per < rows ? r0 + per : rows;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  const int cw = C < 256 ? C : 256, rg = 256 / cw;
+  const int c_in = threadIdx.x % cw, grp = threadIdx.x / cw;
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int c = c0 + c_in;
     float acc = 0.f;
-    for (size_t r = r0; r < r1; ++r) acc += g[r * C + c];
-    partial[(size_t)slab * C + c] = acc;
+    if (grp < rg && c < C)
+      for (size_t r = r0 + grp; r < r1; r += rg) acc += g[r * C + c];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+      for (int k = 1; k < rg; ++k) acc += red[k * cw + c_in];
+      partial[(size_t)slab * C + c] = acc;
+    }
+    __syncthreads();
   }
 }
 __global__ void reduce_slabs_kernel(const float* partial, size_t n, int nslab, float* out) {
@@ -355,46 +367,6 @@ int launch_transpose_w(const float* w, float* wt, int cin, int cout, int cout_pa
   return WCT_OK;
 }
 
-// ---------------------------------------------------------------------------
-// the two GEMMs
-// ---------------------------------------------------------------------------
-// data gradient w.r.t. the conv's (unpadded, possibly upsampled) input: gin [B][H][W][cin]
-//   g [B][H][W][cout] (already masked), wt = transpose_w(W) [(tap,co)][cin]; col / gp are workspaces
-int launch_conv_dgrad(const float* g, const float* wt, int B, int H, int W, int cin, int cout,
-                      float* col /* B*(H+2)*(W+2)*9*cout */, float* gp /* B*(H+2)*(W+2)*cin */, float* gin, hipStream_t s) {
-  int rc;
-  if ((rc = launch_im2col_grad(g, col, B, H, W, cout, s))) return rc;
-  GemmArgs a = {};
-  const int Mp = B * (H + 2) * (W + 2), K = 9 * cout;
-  a.A = col; a.lda = K; a.a_kmajor = 0;
-  a.B = wt; a.ldb = cin; a.b_kmajor = 1;
-  a.M = Mp; a.N = cin; a.K = K; a.ksplit = K;
-  a.out32 = gp; a.ldo = cin;
-  if ((rc = launch_gemm(a, 1, 1, s))) return rc;
-  return launch_reflect_fold(gp, gin, B, H, W, cin, s);
-}
-// weight gradient dW [9*cin][cout] (HWIO): x16 is the conv's fp16 input activation (before the folded upsample)
-int launch_conv_wgrad(const half_t* x16, int upsample, const float* g, int ldg, int B, int H, int W, int cin, int cout,
-                      float* col /* B*H*W*9*cin */, float* partial /* nsplit*9*cin*cout */, int nsplit, float* dw, hipStream_t s) {
-  int rc;
-  if ((rc = launch_im2col_act(x16, col, B, H, W, cin, upsample, s))) return rc;
-  const int P = B * H * W;
-  GemmArgs a = {};
-  a.A = col; a.lda = 9 * cin; a.a_kmajor = 1;
-  a.B = g; a.ldb = ldg; a.b_kmajor = 1;          // ldg >= cout (the 3-channel gradient comes padded to 4)
-  a.M = 9 * cin; a.N = cout; a.K = P;
-  a.ksplit = ((P + nsplit - 1) / nsplit + 15) / 16 * 16;
-  a.out32 = partial; a.ldo = cout; a.out_split_stride = (size_t)9 * cin * cout;
-  const int ns = (P + a.ksplit - 1) / a.ksplit;
-  if ((rc = launch_gemm(a, ns, 1, s))) return rc;
-  return launch_reduce_slabs(partial, (size_t)9 * cin * cout, ns, dw, s);
-}
-int conv_wgrad_splits(int B, int H, int W) {
-  const long P = (long)B * H * W;
-  long n = P / 2048;
-  return (int)(n < 1 ? 1 : (n > 128 ? 128 : n));
-}
-
 // conv1_1 (folded preprocess) data gradient: 64 -> 3.  g [B][H][W][64] masked; wf = folded weights [27][64]
 // (tap*3 + c major); output over the PADDED grid gp [B][H+2][W+2][3] (fold it with launch_reflect_fold)
 __global__ void conv_first_dgrad_kernel(const float* g, const float* wf, float* gp, int B, int H, int W) {
@@ -420,4 +392,235 @@ int launch_conv_first_dgrad(const float* g, const float* wf, float* gp, int B, i
   hipLaunchKernelGGL(conv_first_dgrad_kernel, dim3(tr_blocks((size_t)B * (H + 2) * (W + 2), 256, 65535)), dim3(256), 0, s, g, wf, gp, B, H, W);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Split-operand GEMM for the backward pass: D[m][n] = sum_k A(m,k) B(k,n) / (sa sb) on v_mfma_f32_32x32x16_f16.
+// fp32 operands are scaled by a power of two and split into fp16 hi + lo at staging (22 significand bits, as in
+// the covariance / apply kernels of wct.hip); an operand whose values are exact fp16 numbers (saved activations)
+// skips its lo half.  A(m,k) = AKM ? A[k*lda+m] : A[m*lda+k];  B(k,n) = BKM ? B[k*ldb+n] : B[n*ldb+k].
+// Block = 128 x BN tile, 256 threads = 2x2 waves, K-stage 32, split-K over blockIdx.z (partials reduced in a fixed
+// order by the caller).  The data gradient runs <0,1> (rows of the im2col'ed gradient x transposed weights), the
+// weight gradient <1,1> (im2col'ed activations^T x gradient).
+// ---------------------------------------------------------------------------
+struct SplitGemmArgs {
+  const float* A; int lda; const float* B; int ldb;
+  int M, N, K, ksplit;
+  const float* a_scale; const float* b_scale;    // device scalars (power of two) or null = 1
+  int a_exact16, b_exact16;                       // operand values are exact fp16 numbers: no lo half
+  float* out; int ldo; size_t out_split_stride;
+};
+
+template <int BX, bool KM>
+struct SplitStage {
+  // one operand tile: BX rows x 32 k.  KM (k-major source): thread = (row, k-group) with 32*BX/256 strided scalar
+  // loads, coalesced over the rows; row-major source: thread = 16-B pieces of 8 consecutive k
+  static constexpr int N = KM ? BX * 32 / 256 : (BX * 4 / 256) * 8;
+  float v[N];
+  __device__ __forceinline__ void load(const float* src, int ld, int x0, int X, int k0, int kend, int tid) {
+    if (KM) {
+      const int r = tid % BX, kg = tid / BX;
+      const bool ok = x0 + r < X;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const int k = k0 + kg * N + j;
+        v[j] = (ok && k < kend) ? src[(size_t)k * ld + x0 + r] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N / 8; ++i) {
+        const int item = tid + i * 256, row = item >> 2, kq = item & 3;
+        const bool ok = x0 + row < X;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int k = k0 + kq * 8 + h * 4;
+          f32x4 t = {0.f, 0.f, 0.f, 0.f};
+          if (ok && k < kend) t = *reinterpret_cast<const f32x4*>(src + (size_t)(x0 + row) * ld + k);   // K % 4 == 0
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i * 8 + h * 4 + j] = t[j];
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(unsigned char* hi, unsigned char* lo, float sc, bool exact16, int tid) const {
+#pragma unroll
+    for (int q = 0; q < N / 8; ++q) {
+      int row, chunk;
+      if (KM) { row = tid % BX; chunk = (tid / BX) * (N / 8) + q; }
+      else { const int item = tid + q * 256; row = item >> 2; chunk = item & 3; }
+      half8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = v[q * 8 + j] * sc;
+        h[j] = (half_t)x;
+        l[j] = (half_t)(x - (float)h[j]);
+      }
+      const int off = (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16;
+      *reinterpret_cast<half8*>(hi + off) = h;
+      if (!exact16) *reinterpret_cast<half8*>(lo + off) = l;
+    }
+  }
+};
+
+template <int BN, bool AKM, bool BKM>
+__global__ __launch_bounds__(256, 2) void gemm_f16x2_kernel(SplitGemmArgs p) {
+  constexpr int BM = 128, TM = 2, TN = BN / 64;
+  __shared__ __attribute__((aligned(16))) unsigned char la[2][BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char lb[2][BN * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int split = blockIdx.z;
+  const int kbeg = split * p.ksplit, kend = min(p.K, kbeg + p.ksplit);
+  const float sa = p.a_scale ? *p.a_scale : 1.f, sb = p.b_scale ? *p.b_scale : 1.f;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  SplitStage<BM, AKM> sA;
+  SplitStage<BN, BKM> sB;
+  if (kbeg < kend) { sA.load(p.A, p.lda, m0, p.M, kbeg, kend, tid); sB.load(p.B, p.ldb, n0, p.N, kbeg, kend, tid); }
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    sA.store(la[0], la[1], sa, p.a_exact16, tid);
+    sB.store(lb[0], lb[1], sb, p.b_exact16, tid);
+    __syncthreads();
+    if (k0 + 32 < kend) { sA.load(p.A, p.lda, m0, p.M, k0 + 32, kend, tid); sB.load(p.B, p.ldb, n0, p.N, k0 + 32, kend, tid); }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = ks * 2 + (lane >> 5);
+      half8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = (wm * TM + i) * 32 + (lane & 31);
+        const int off = (r * 4 + (chunk ^ ((r >> 2) & 3))) * 16;
+        ah[i] = *reinterpret_cast<const half8*>(la[0] + off);
+        if (!p.a_exact16) al[i] = *reinterpret_cast<const half8*>(la[1] + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int r = (wn * TN + j) * 32 + (lane & 31);
+        const int off = (r * 4 + (chunk ^ ((r >> 2) & 3))) * 16;
+        bh[j] = *reinterpret_cast<const half8*>(lb[0] + off);
+        if (!p.b_exact16) bl[j] = *reinterpret_cast<const half8*>(lb[1] + off);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (!p.a_exact16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          if (!p.b_exact16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  const float inv = 1.f / (sa * sb);
+  float* out = p.out + (size_t)split * p.out_split_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (gm < p.M && gn < p.N) out[(size_t)gm * p.ldo + gn] = acc[i][j][r] * inv;
+      }
+    }
+}
+
+template <bool AKM, bool BKM>
+static int launch_split_gemm(const SplitGemmArgs& a, int nsplit, hipStream_t s) {
+  if (a.N > 64) {
+    dim3 grid(cdiv(a.N, 128), cdiv(a.M, 128), nsplit);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<128, AKM, BKM>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid(cdiv(a.N, 64), cdiv(a.M, 128), nsplit);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<64, AKM, BKM>), grid, dim3(256), 0, s, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// power-of-two scale that brings max |x| to [8192, 16384) (1 for an all-zero / non-finite input); the max of
+// non-negative floats is the max of their bit patterns, so the atomics commute
+__global__ void absmax_bits_kernel(const float* x, size_t n4, unsigned* bits) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (m < 3e38f) atomicMax(bits, __float_as_uint(m));          // one atomic per block
+  }
+}
+__global__ void scale_from_bits_kernel(const unsigned* bits, float* scale) {
+  const float m = __uint_as_float(*bits);
+  float sc = 1.f;
+  if (m > 0.f && m < 1e30f) { int e; frexpf(m, &e); sc = ldexpf(1.f, 14 - e); }
+  *scale = sc;
+}
+// scratch: 2 dwords (bits, scale); n must be a multiple of 4 (every gradient tensor here is)
+int launch_pow2_scale(const float* x, size_t n, void* scratch, hipStream_t s) {
+  ARG_CHECK(n % 4 == 0);
+  unsigned* bits = reinterpret_cast<unsigned*>(scratch);
+  float* scale = reinterpret_cast<float*>(scratch) + 1;
+  HIP_TRY(hipMemsetAsync(bits, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(absmax_bits_kernel, dim3(tr_blocks(n / 4, 256 * 8, 512)), dim3(256), 0, s, x, n / 4, bits);
+  hipLaunchKernelGGL(scale_from_bits_kernel, dim3(1), dim3(1), 0, s, bits, scale);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the two GEMMs of a conv layer's backward pass (scratch: 2 dwords for the gradient's power-of-two scale)
+// ---------------------------------------------------------------------------
+// data gradient w.r.t. the conv's (unpadded, possibly upsampled) input: gin [B][H][W][cin]
+//   g [B][H][W][cout] (already masked), wt = transpose_w(W) [(tap,co)][cin]; col / gp are workspaces
+int launch_conv_dgrad(const float* g, const float* wt, int B, int H, int W, int cin, int cout,
+                      float* col /* B*(H+2)*(W+2)*9*cout */, float* gp /* B*(H+2)*(W+2)*cin */, float* gin,
+                      void* scratch, hipStream_t s) {
+  int rc;
+  const float* gscale = reinterpret_cast<const float*>(scratch) + 1;       // launch_pow2_scale(g) ran on this scratch
+  if ((rc = launch_im2col_grad(g, col, B, H, W, cout, s))) return rc;
+  SplitGemmArgs a = {};
+  const int Mp = B * (H + 2) * (W + 2), K = 9 * cout;
+  a.A = col; a.lda = K; a.B = wt; a.ldb = cin;
+  a.M = Mp; a.N = cin; a.K = K; a.ksplit = (K + 31) / 32 * 32;
+  a.a_scale = gscale; a.b_scale = nullptr; a.a_exact16 = 0; a.b_exact16 = 0;
+  a.out = gp; a.ldo = cin; a.out_split_stride = 0;
+  if ((rc = launch_split_gemm<false, true>(a, 1, s))) return rc;
+  return launch_reflect_fold(gp, gin, B, H, W, cin, s);
+}
+// weight gradient dW [9*cin][cout] (HWIO): x16 is the conv's fp16 input activation (before the folded upsample);
+// g has row pitch ldg >= cout (the 3-channel gradient comes padded to 4)
+int launch_conv_wgrad(const half_t* x16, int upsample, const float* g, int ldg, int B, int H, int W, int cin, int cout,
+                      float* col /* B*H*W*9*cin */, float* partial /* nsplit*9*cin*cout */, int nsplit, float* dw,
+                      void* scratch, hipStream_t s) {
+  int rc;
+  const float* gscale = reinterpret_cast<const float*>(scratch) + 1;       // launch_pow2_scale(g) ran on this scratch
+  const int P = B * H * W;
+  if ((rc = launch_im2col_act(x16, col, B, H, W, cin, upsample, s))) return rc;
+  SplitGemmArgs a = {};
+  a.A = col; a.lda = 9 * cin; a.B = g; a.ldb = ldg;
+  a.M = 9 * cin; a.N = cout; a.K = P;
+  a.ksplit = ((P + nsplit - 1) / nsplit + 31) / 32 * 32;
+  a.a_scale = nullptr; a.b_scale = gscale; a.a_exact16 = 1; a.b_exact16 = 0;      // activations are exact fp16 values
+  a.out = partial; a.ldo = cout; a.out_split_stride = (size_t)9 * cin * cout;
+  const int ns = (P + a.ksplit - 1) / a.ksplit;
+  if ((rc = launch_split_gemm<true, true>(a, ns, s))) return rc;
+  return launch_reduce_slabs(partial, (size_t)9 * cin * cout, ns, dw, s);
+}
+int conv_wgrad_splits(int B, int H, int W) {
+  const long P = (long)B * H * W;
+  long n = P / 2048;
+  return (int)(n < 1 ? 1 : (n > 128 ? 128 : n));
 }
