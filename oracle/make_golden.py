@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 sys.path.insert(0, os.path.dirname(HERE))
 
-from wct_tf_amd.weights import synthetic_features  # noqa: E402  (seeded inputs only)
+from wct_tf_amd.weights import synthetic_features, synthetic_features_exact, synthetic_weights  # noqa: E402  (seeded inputs only)
 
 
 def lift_function(path, name):
@@ -45,9 +45,119 @@ WCT_CASES = [
 ]
 
 
+# The WCT shapes of BASELINE configs 2-4 (512x512 content and style): (C, N) per level.  The reference's wct_np is
+# run at the full size; the fixture keeps a DIGEST of its output (the arrays themselves are 8-67 MB each):
+#   rows     256 seeded pixel rows of the output, verbatim
+#   sketch   S . out for 32 seeded +-1 vectors over the pixel axis (float64): any error in any pixel shows up here
+#            with the same relative size (E|s.d|^2 = |d|^2)
+#   mean/sq  per-channel mean and mean square of the output (float64)
+# and rebuilds the inputs from their seeds (synthetic_features_exact); in_probe pins that rebuild.
+SIZE_CASES = [
+    # name, C, h, w (content and style alike), alpha, content seed, style seed
+    ('relu5_1_512x1024', 512, 32, 32, 0.8, 7105, 7205),
+    ('relu4_1_512x4096', 512, 64, 64, 0.8, 7104, 7204),
+    ('relu3_1_256x16384', 256, 128, 128, 0.8, 7103, 7203),
+    ('relu2_1_128x65536', 128, 256, 256, 0.8, 7102, 7202),
+    ('relu1_1_64x262144', 64, 512, 512, 0.8, 7101, 7201),
+]
+N_ROWS, N_SKETCH = 256, 32
+
+
+def size_case_inputs(case):
+    name, c, h, w, alpha, sc, ss = case
+    return synthetic_features_exact(sc, c, h, w, 2.0), synthetic_features_exact(ss, c, h, w, 2.0)
+
+
+def digest_selectors(case):
+    """Seeded row indices and +-1 sketch vectors of a size case (integers: identical on every host)."""
+    name, c, h, w, alpha, sc, ss = case
+    rng = np.random.default_rng(sc * 31 + 7)
+    rows = np.sort(rng.choice(h * w, N_ROWS, replace=False))
+    signs = rng.integers(0, 2, (N_SKETCH, h * w)).astype(np.float64) * 2 - 1
+    return rows, signs
+
+
+def in_probe(x):
+    x = np.asarray(x, np.float64)
+    return np.array([x.sum(), (x * x).sum(), x.reshape(-1)[::9973].sum()])
+
+
+def hard_feature_cases():
+    """Feature maps with the defects real VGG features have and Gaussian-mixed ones do not (hard parts
+    2 and 5): channels that are exactly dead, exactly duplicated channels, post-ReLU sparsity."""
+    cases = {}
+    fc = synthetic_features(301, 64, 24, 24, 2.0)
+    fs = synthetic_features(302, 64, 20, 28, 2.0)
+    fc[..., [3, 17, 40]] = 0
+    fs[..., [5, 17]] = 0
+    cases['dead_channels'] = (fc, fs, 0.8)
+    fc = synthetic_features(303, 64, 24, 24, 2.0)
+    fs = synthetic_features(304, 64, 24, 24, 2.0)
+    fc[..., 9] = fc[..., 8]
+    fc[..., 33] = fc[..., 8]
+    fs[..., 21] = fs[..., 20]
+    cases['duplicated_channels'] = (fc, fs, 0.8)
+    fc = synthetic_features(305, 128, 28, 28, 1.5)
+    fs = synthetic_features(306, 128, 28, 28, 1.5)
+    fc = np.maximum(fc - np.quantile(fc, 0.8, axis=(0, 1, 2), keepdims=True), 0).astype(np.float32)   # 80 % zeros per channel
+    fs = np.maximum(fs - np.quantile(fs, 0.8, axis=(0, 1, 2), keepdims=True), 0).astype(np.float32)
+    cases['sparse_post_relu'] = (fc, fs, 0.6)
+    return cases
+
+
+def gilbert_fixture():
+    """samples/gilbert.jpg (the reference's only content photo) -> two 96x96 uint8 crops (Pillow,
+    area-averaged to 1/3 size first).  The photo is an input sample, not source; only these crops are kept."""
+    from PIL import Image
+    img = Image.open(os.path.join(REF, 'samples', 'gilbert.jpg')).convert('RGB')
+    wd, ht = img.size
+    small = np.asarray(img.resize((wd // 3, ht // 3), Image.BOX))
+    h, w, _ = small.shape
+    a = small[(h - 96) // 2:(h - 96) // 2 + 96, (w - 96) // 2:(w - 96) // 2 + 96]
+    b = small[:96, :96][:, ::-1]
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_wct_np = lift_function(os.path.join(REF, 'ops.py'), 'wct_np')
+
+    # ---- the reference at the metric's own WCT shapes (digests) ----
+    blob = {}
+    for case in SIZE_CASES:
+        name, c, h, w, alpha = case[:5]
+        fc, fs = size_case_inputs(case)
+        out = ref_wct_np(fc, fs, alpha)
+        assert out.dtype == np.float32 and out.shape == fc.shape
+        o = out.reshape(h * w, c)
+        rows, signs = digest_selectors(case)
+        blob[name + '/rows'] = o[rows]
+        blob[name + '/sketch'] = signs @ o.astype(np.float64)
+        blob[name + '/mean'] = o.astype(np.float64).mean(0)
+        blob[name + '/sq'] = (o.astype(np.float64) ** 2).mean(0)
+        blob[name + '/in_probe'] = np.stack([in_probe(fc), in_probe(fs)])
+        print(name, 'done')
+    np.savez_compressed(os.path.join(OUT, 'wct_np_sizes.npz'), **blob)
+
+    # ---- defective / realistic feature maps, inputs and reference outputs in full ----
+    blob = {}
+    for name, (fc, fs, alpha) in hard_feature_cases().items():
+        blob[name + '/content'], blob[name + '/style'] = fc, fs
+        blob[name + '/alpha'] = np.float64(alpha)
+        blob[name + '/out'] = ref_wct_np(fc, fs, alpha)
+    ga, gb = gilbert_fixture()
+    np.savez_compressed(os.path.join(OUT, 'gilbert_96.npz'), content=ga, style=gb)
+    from oracle import net_oracle
+    wts = synthetic_weights(42)
+    fa = net_oracle.encode(np.float32(ga / 255.), wts, ['relu3_1', 'relu4_1'])
+    fb = net_oracle.encode(np.float32(gb / 255.), wts, ['relu3_1', 'relu4_1'])
+    for relu in ('relu3_1', 'relu4_1'):          # relu4_1: 12x12 = 144 pixels < 512 channels (rank-deficient by size)
+        fc, fs = fa[relu][None], fb[relu][None]
+        blob['gilbert_' + relu + '/content'], blob['gilbert_' + relu + '/style'] = fc, fs
+        blob['gilbert_' + relu + '/alpha'] = np.float64(0.8)
+        blob['gilbert_' + relu + '/out'] = ref_wct_np(fc, fs, 0.8)
+    np.savez_compressed(os.path.join(OUT, 'wct_np_hard.npz'), **blob)
+
     blob = {}
     for i, (name, c, (hc, wc), (hs, ws), alpha, dec, rank) in enumerate(WCT_CASES):
         content = synthetic_features(100 + i, c, hc, wc, dec, rank)

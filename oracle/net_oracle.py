@@ -107,9 +107,18 @@ def upsample2x_nearest(x):
     return np.repeat(np.repeat(x, 2, axis=0), 2, axis=1)
 
 
-def encode(img01, weights, targets):
+def _h16(a):
+    return np.asarray(a, np.float16).astype(np.float32)
+
+
+def encode(img01, weights, targets, fp16_storage=False):
     """Run the shared VGG on an HxWx3 image in [0,1]; return {relu: features}
-    for every relu name in `targets` (model.py:60-75,135-139)."""
+    for every relu name in `targets` (model.py:60-75,135-139).
+
+    fp16_storage=True restates the SAME graph with the storage precision of the MI355X path: 3x3
+    filters (conv1_1 excepted: it runs on split fp16 pairs, 22 bits) and the activations handed
+    from layer to layer are rounded to fp16, sums and the tapped feature maps stay fp32.  It is not
+    a reference mode; it lets the stack tests use a tolerance that shows accumulation order only."""
     enc = weights['encoder']
     want = set(targets)
     deepest = sorted(want)[-1]                       # model.py:60
@@ -118,27 +127,37 @@ def encode(img01, weights, targets):
     for layer in ENCODER_LAYERS:
         if layer[0] == 'C':
             name = layer[1]
-            x = conv3x3_reflect(x, enc[name][0], enc[name][1], relu=True)
+            w = enc[name][0]
+            if fp16_storage and name != 'conv1_1':
+                w = _h16(w)
+            x = conv3x3_reflect(x, w, enc[name][1], relu=True)
             relu = 'relu' + name[4:]
             if relu in want:
                 feats[relu] = x
             if relu == deepest:
                 break
+            if fp16_storage:
+                x = _h16(x)
         else:
             x = maxpool2x2_same(x)
     return feats
 
 
-def decode(feat, weights, relu_target):
-    """Mirror decoder for `relu_target` (model.py:245-304)."""
+def decode(feat, weights, relu_target, fp16_storage=False):
+    """Mirror decoder for `relu_target` (model.py:245-304).  fp16_storage: see encode (the decoder's input, every
+    filter and every hand-over between layers in fp16; the 3-channel image stays fp32)."""
     x = np.asarray(feat, np.float32)
+    if fp16_storage:
+        x = _h16(x)
     params = weights['decoder'][relu_target]
     i = 0
     for kind, cin, cout, relu in decoder_layers(relu_target):
         if kind == 'C':
             w, b = params[i]
             i += 1
-            x = conv3x3_reflect(x, w, b, relu=relu)
+            x = conv3x3_reflect(x, _h16(w) if fp16_storage else w, b, relu=relu)
+            if fp16_storage and cout != 3:
+                x = _h16(x)
         else:
             x = upsample2x_nearest(x)
     return x
@@ -155,7 +174,8 @@ def postprocess(image01):
 
 
 def stylize(content, style, weights, relu_targets, alpha=1.0, adain=False,
-            wct_mode='tf', return_levels=False, swap5=False, ss_alpha=0.6, ss_patch_size=3, ss_stride=1):
+            wct_mode='tf', return_levels=False, swap5=False, ss_alpha=0.6, ss_patch_size=3, ss_stride=1,
+            fp16_storage=False):
     """One WCT.predict (wct.py:70-106) through the test-mode graph
     (model.py:33-94,123-176): ONE style pass with all taps; levels in
     `relu_targets` order; level i>0 encodes clip(previous decoded, 0, 1)
@@ -166,13 +186,13 @@ def stylize(content, style, weights, relu_targets, alpha=1.0, adain=False,
     """
     c01 = np.float32(preprocess(content))
     s01 = np.float32(preprocess(style))
-    style_feats = encode(s01, weights, relu_targets)
+    style_feats = encode(s01, weights, relu_targets, fp16_storage)     # fp16_storage: see encode (not a reference mode)
     x = c01
     levels = []
     for i, relu in enumerate(relu_targets):
         if i > 0:
             x = np.clip(x, 0, 1)
-        fc = encode(x, weights, [relu])[relu]
+        fc = encode(x, weights, [relu], fp16_storage)[relu]
         fs = style_feats[relu]
         if swap5 and relu == 'relu5_1':          # tf.case priority swap5 > adain > wct (model.py:148-154)
             t = wct_oracle.wct_style_swap(fc, fs, ss_alpha, ss_patch_size, ss_stride)[0]
@@ -182,7 +202,7 @@ def stylize(content, style, weights, relu_targets, alpha=1.0, adain=False,
             t = wct_oracle.wct_tf(fc, fs, alpha)[0]
         else:
             t = wct_oracle.wct_np(fc, fs, alpha)[0]
-        x = decode(t, weights, relu)
+        x = decode(t, weights, relu, fp16_storage)
         if return_levels:
             levels.append((fc, fs, t, x))
     out = postprocess(x)

@@ -20,8 +20,13 @@ def _unflatten(mat, shape):
     return np.transpose(mat.reshape(c, h, w), (1, 2, 0))[None]
 
 
-def wct_np(content, style, alpha=0.6, eps=1e-5):
+def wct_np(content, style, alpha=0.6, eps=1e-5, keep=None):
     """Whiten-colour transform, NumPy semantics of ops.py:92-140.
+
+    `keep` = (kc, ks) is NOT a reference argument: it overrides the number of singular values
+    kept on the content / style side (the reference keeps those > 1e-5, ops.py:112,125).  Tests
+    use it only to enumerate the outcomes that are legitimate when an eigenvalue sits within
+    fp32 noise of that threshold (tests/test_gpu_fuzz.py).
 
     * no eps on the covariance (ops.py:108,121)
     * keep singular values > 1e-5 (ops.py:112,125)
@@ -39,7 +44,7 @@ def wct_np(content, style, alpha=0.6, eps=1e-5):
     fc = fc_full - mc
     cov_c = np.dot(fc, fc.T) / (nc - 1)
     ec, wc, _ = np.linalg.svd(cov_c)
-    kc = int((wc > 1e-5).sum())
+    kc = int((wc > 1e-5).sum()) if keep is None else int(keep[0])
     dc = np.diag((wc[:kc] + eps) ** -0.5)
     whitened = ec[:, :kc].dot(dc).dot(ec[:, :kc].T).dot(fc)
 
@@ -47,7 +52,7 @@ def wct_np(content, style, alpha=0.6, eps=1e-5):
     fs = fs_full - ms
     cov_s = np.dot(fs, fs.T) / (ns - 1)
     es, ws, _ = np.linalg.svd(cov_s)
-    ks = int((ws > 1e-5).sum())
+    ks = int((ws > 1e-5).sum()) if keep is None else int(keep[1])
     ds = np.sqrt(np.diag(ws[:ks] + eps))
     colored = es[:, :ks].dot(ds).dot(es[:, :ks].T).dot(whitened) + ms
 
@@ -55,8 +60,11 @@ def wct_np(content, style, alpha=0.6, eps=1e-5):
     return np.float32(_unflatten(blended, cshape))
 
 
-def wct_tf(content, style, alpha, eps=1e-8):
+def wct_tf(content, style, alpha, eps=1e-8, keep=None):
     """Whiten-colour transform, TensorFlow-graph semantics of ops.py:24-90.
+
+    `keep` = (kc, ks): test-only override of the kept counts, see wct_np (the reference keeps
+    singular values > 1e-5, ops.py:68-69).
 
     * eps*I added to both covariances (ops.py:45,50)
     * keep singular values > 1e-5 (ops.py:68-69)
@@ -80,8 +88,8 @@ def wct_tf(content, style, alpha, eps=1e-8):
 
     uc, sc, _ = np.linalg.svd(cov_c)
     us, ss, _ = np.linalg.svd(cov_s)
-    kc = int((sc > 1e-5).sum())
-    ks = int((ss > 1e-5).sum())
+    kc = int((sc > 1e-5).sum()) if keep is None else int(keep[0])
+    ks = int((ss > 1e-5).sum()) if keep is None else int(keep[1])
 
     dc = np.diag(sc[:kc] ** np.float32(-0.5))
     whitened = uc[:, :kc].dot(dc).dot(uc[:, :kc].T).dot(fc)

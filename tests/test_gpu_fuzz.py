@@ -20,6 +20,7 @@ from wct_tf_amd import _lib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+STATS = {'wct_cases': 0, 'wct_near_cutoff': 0}
 
 
 @pytest.fixture(scope='module')
@@ -48,18 +49,41 @@ def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_s
     scale = 10.0 ** log_scale
     nc, ns = hc * wc, hs * ws
     fc, fs = features(rng, nc, c, scale), features(rng, ns, c, scale * 10.0 ** rng.uniform(-1, 1))
-    want = (oracle.wct_np if mode == 'np' else oracle.wct_tf)(fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c), alpha)
-    want = np.asarray(want).reshape(nc, c)
+    fn = oracle.wct_np if mode == 'np' else oracle.wct_tf
     got = ctx.transform(fc, fs, alpha, _lib.WCT_NP if mode == 'np' else _lib.WCT_TF)
-    # at tiny scales the reference's absolute 1e-5 eigenvalue cut-off decides which directions survive; an
-    # eigenvalue within fp32 noise of the cut-off may fall on either side -- compare where that cannot happen
-    cov = np.cov(np.float64(fc).T) if nc > 1 else np.zeros((c, c))
-    ev = np.linalg.eigvalsh(cov + (1e-8 if mode == 'tf' else 0) * np.eye(c))
-    near_cut = np.any(np.abs(ev - 1e-5) < 2e-6 + 1e-4 * np.abs(ev).max() * 1e-2)
-    if near_cut and alpha > 0:
-        return
     assert np.all(np.isfinite(got))
-    assert rel_err(got, want) < 1e-3, (c, nc, ns, alpha, mode, log_scale)
+    # The reference drops eigenvalues <= 1e-5 (absolute, ops.py:68-69 / 112,125).  At tiny feature scales an
+    # eigenvalue can sit within fp32 noise of that threshold (these covariances are not graded: the noise of ANY
+    # fp32 evaluation, NumPy's included, is ~1e-6 ||A||), and keeping or dropping it are both legitimate readings
+    # of the reference.  Criterion, also for those cases: the result must match the oracle for SOME kept count
+    # inside the noise band on each side -- and exactly the reference's count when no eigenvalue is in the band.
+    eps_cov = 1e-8 if mode == 'tf' else 0.0
+    ranges = []
+    for x in (fc, fs):
+        ev = np.linalg.eigvalsh((np.cov(np.float64(x).T) if x.shape[0] > 1 else np.zeros((c, c))) + eps_cov * np.eye(c))
+        band = 2e-6 + 1e-6 * np.abs(ev).max()
+        ranges.append((int((ev > 1e-5 + band).sum()), int((ev > 1e-5 - band).sum())))
+    near = ranges[0][0] != ranges[0][1] or ranges[1][0] != ranges[1][1]
+    STATS['wct_cases'] += 1
+    if not near or alpha == 0:
+        want = np.asarray(fn(fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c), alpha)).reshape(nc, c)
+        assert rel_err(got, want) < 1e-3, (c, nc, ns, alpha, mode, log_scale)
+        return
+    STATS['wct_near_cutoff'] += 1
+    errs = {}
+    for kc in range(ranges[0][0], ranges[0][1] + 1):
+        for ks in range(ranges[1][0], ranges[1][1] + 1):
+            want = np.asarray(fn(fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c), alpha, keep=(kc, ks))).reshape(nc, c)
+            errs[(kc, ks)] = rel_err(got, want)
+    print('near cut-off: C=%d scale 1e%.1f kept-count candidates %s -> best rel %.2e' % (c, log_scale, ranges, min(errs.values())))
+    assert min(errs.values()) < 1e-3, (c, nc, ns, alpha, mode, log_scale, errs)
+
+
+def test_wct_random_shapes_report():
+    """Runs after the sweep above: how many of its cases had an eigenvalue inside the noise band of the cut-off
+    (those were checked against the band of legitimate outcomes instead of being skipped)."""
+    print('WCT sweep: %(wct_cases)d cases, %(wct_near_cutoff)d with an eigenvalue within fp32 noise of the 1e-5 cut-off' % STATS)
+    assert STATS['wct_cases'] >= 30
 
 
 @settings(max_examples=15, **COMMON)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, rel_err, max_rel
+from conftest import GOLDEN, rel_err, max_rel, check_against_size_digest
 from wct_tf_amd import _lib
 from wct_tf_amd.weights import synthetic_features, synthetic_weights, synthetic_image
 
@@ -134,6 +134,78 @@ def test_wct_config_sizes(ctx):
         fc = synthetic_features(40 + c, c, h, w, 2.0)
         fs = synthetic_features(50 + c, c, h, w, 2.0)
         _check_wct(ctx, fc, fs, 0.8 if c != 64 else 1.0, 'np')
+
+
+def test_wct_matches_reference_at_config_sizes(ctx):
+    """BASELINE configs 2-4: the five WCT shapes of a 512x512 frame, (C, N) = (512,1024) (512,4096) (256,16384)
+    (128,65536) (64,262144).  wct_np semantics against the digest of the REFERENCE's own wct_np run at that size
+    (tests/golden/wct_np_sizes.npz, ops.py:92-140); wct_tf semantics against the oracle (ops.py:24-90).
+    Tolerance: 1e-3 relative (north star), on the sampled rows, on the +-1 sketch over all pixels and on the
+    per-channel moments."""
+    from oracle.make_golden import SIZE_CASES, size_case_inputs, in_probe
+    z = np.load(os.path.join(GOLDEN, 'wct_np_sizes.npz'))
+    for case in SIZE_CASES:
+        name, c, h, w, alpha = case[:5]
+        fc, fs = size_case_inputs(case)
+        assert np.allclose(np.stack([in_probe(fc), in_probe(fs)]), z[name + '/in_probe'], rtol=1e-6), name
+        got, sweeps = ctx.transform(fc.reshape(-1, c), fs.reshape(-1, c), alpha, _lib.WCT_NP, return_sweeps=True)
+        errs = check_against_size_digest(z, case, got, WCT_TOL)
+        want = oracle.wct_np(fc, fs, alpha)          # pinned to the same digest in tests/test_oracle.py
+        e_full = rel_err(got.reshape(want.shape), want)
+        print('%s sweeps=%s rows %.2e sketch %.2e sq %.2e | full output vs oracle %.2e' % ((name, sweeps) + errs + (e_full,)))
+        assert e_full < WCT_TOL and max_rel(got.reshape(want.shape), want) < 5 * WCT_TOL
+        _check_wct(ctx, fc, fs, alpha, 'tf')
+
+
+def test_wct_matches_reference_on_defective_and_real_image_features(ctx):
+    """Exactly dead channels, exactly duplicated channels, 80 %-sparse post-ReLU maps, and features of the reference's
+    sample photo (relu3_1 and the rank-deficient relu4_1: 144 pixels, 512 channels): wct_np semantics against the
+    reference's own outputs (tests/golden/wct_np_hard.npz), wct_tf semantics against the oracle."""
+    z = np.load(os.path.join(GOLDEN, 'wct_np_hard.npz'))
+    names = sorted({k.split('/')[0] for k in z.files})
+    assert len(names) == 5
+    for n in names:
+        fc, fs, ref, alpha = z[n + '/content'], z[n + '/style'], z[n + '/out'], float(z[n + '/alpha'])
+        c = fc.shape[-1]
+        got, sweeps = ctx.transform(fc.reshape(-1, c), fs.reshape(-1, c), alpha, _lib.WCT_NP, return_sweeps=True)
+        got = got.reshape(ref.shape)
+        print('%s C=%d sweeps=%s rel %.2e max %.2e' % (n, c, sweeps, rel_err(got, ref), max_rel(got, ref)))
+        assert np.all(np.isfinite(got)), n
+        assert rel_err(got, ref) < WCT_TOL and max_rel(got, ref) < 5 * WCT_TOL, n
+        _check_wct(ctx, fc, fs, alpha, 'tf')
+
+
+def _graded_features(rng, n, c, decades):
+    """Channels with log-spaced scales over `decades` and mild mixing: a graded covariance D H D with a
+    well-conditioned H, the structure real feature maps have (tiny-variance channels), for which fp32
+    arithmetic -- the reference's as much as ours -- keeps the small eigenvalues to high RELATIVE accuracy."""
+    mix = np.eye(c) + 0.3 * rng.standard_normal((c, c)) / np.sqrt(c)
+    d = 10.0 ** (-np.arange(c) * decades / (c - 1) / 2)
+    return np.maximum(rng.standard_normal((n, c)) @ mix + 0.3, 0) * d
+
+
+def test_wct_cutoff_straddle(ctx):
+    """SURVEY 7 hard part 2: the 1e-5 eigenvalue cut-off (ops.py:68-69 / 112,125).  The features are scaled so that
+    the cut-off falls in the geometric middle of the gap between two neighbouring eigenvalues (each ~12 % away, far
+    beyond fp32 noise on a graded matrix): one is kept with a gain of ~300, the next is dropped.  A solver that
+    mis-places either changes the output by O(1/sqrt(kept)), a hundred times the tolerance."""
+    rng = np.random.default_rng(77)
+    c, h, w = 64, 48, 48
+    for trial in range(3):
+        feats = []
+        for side in range(2):
+            x = _graded_features(rng, h * w, c, 7.0)
+            ev = np.sort(np.linalg.eigvalsh(np.cov(np.float32(x).astype(np.float64).T)))
+            k = 8 + 5 * trial + side                     # put the cut-off between eigenvalues k-1 and k
+            x = x * np.sqrt(1e-5 / np.sqrt(ev[k - 1] * ev[k]))
+            x = np.float32(x)
+            ev = np.sort(np.linalg.eigvalsh(np.cov(x.astype(np.float64).T)))
+            lo, hi = ev[ev <= 1e-5].max(), ev[ev > 1e-5].min()
+            assert lo < 0.93e-5 and hi > 1.07e-5, (lo, hi)
+            print('  side %d: %d eigenvalues kept, neighbours of the cut-off %.3e / %.3e' % (side, (ev > 1e-5).sum(), lo, hi))
+            feats.append(x.reshape(1, h, w, c))
+        for mode in ('np', 'tf'):
+            _check_wct(ctx, feats[0], feats[1], 0.8, mode)
 
 
 def test_wct_ops_module_surface(ctx):

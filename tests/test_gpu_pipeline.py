@@ -9,8 +9,12 @@ from wct_tf_amd.weights import synthetic_weights, synthetic_image, RELU_TARGETS
 
 pytestmark = pytest.mark.gpu
 
-# fp16 activations through up to 13 stacked convs
+# fp16 activations through up to 13 stacked convs, against the fp32 oracle: the storage rounding itself is 7.6e-3 at
+# relu5_1 of a 512x512 image (oracle fp32 vs oracle with fp16 storage, measured)
 ENC_TOL = 1e-2
+# against the oracle restated with the same storage precision (oracle.encode/decode(fp16_storage=True)): what is left
+# is the fp32 accumulation order and the few fp16 roundings it flips
+ENC_TOL16 = 1e-3
 
 
 @pytest.fixture(scope='module')
@@ -58,18 +62,30 @@ def test_decoders(ctx, weights, relu, hw):
 
 
 def _teacher_forced(ctx, weights, content, style, targets, alpha, mode):
-    """Run the oracle pipeline; feed each level's oracle inputs to the GPU ops and compare."""
+    """Run the oracle pipeline; feed each level's oracle inputs to the GPU ops and compare: the encoder on the
+    oracle's level input, the transform on the oracle's features, the decoder on the oracle's transformed
+    features -- against the fp32 oracle (ENC_TOL) and against the oracle with fp16 storage (ENC_TOL16)."""
     from wct_tf_amd import _lib
     out, levels = oracle.stylize(content, style, weights, targets, alpha=alpha, wct_mode=mode, return_levels=True)
-    for relu, (fc, fs, t, x) in zip(targets, levels):
+    x_in = np.float32(content / 255.)
+    for i, (relu, (fc, fs, t, x)) in enumerate(zip(targets, levels)):
         c = fc.shape[-1]
+        if i > 0:
+            x_in = np.clip(x_in, 0, 1)
+        got_fc = ctx.encode(x_in, relu)
+        e_enc = rel_err(got_fc, fc[0] if fc.ndim == 4 else fc)
+        e_enc16 = rel_err(got_fc, oracle.encode(x_in, weights, [relu], fp16_storage=True)[relu])
         got_t = ctx.transform(fc.reshape(-1, c), fs.reshape(-1, c), alpha,
                               _lib.WCT_TF if mode == 'tf' else _lib.WCT_NP).reshape(t.shape)
         e = rel_err(got_t, t)
-        print(relu, 'transform rel %.2e' % e)
-        assert e < 1e-3
         got_x = ctx.decode(t, relu)
-        assert rel_err(got_x, x) < ENC_TOL
+        e_dec, e_dec16 = rel_err(got_x, x), rel_err(got_x, oracle.decode(t, weights, relu, fp16_storage=True))
+        print('%s %s: encoder rel %.2e (fp16-storage oracle %.2e)  transform rel %.2e  decoder rel %.2e (fp16-storage oracle %.2e)'
+              % (relu, fc.shape, e_enc, e_enc16, e, e_dec, e_dec16))
+        assert e < 1e-3
+        assert e_enc < ENC_TOL and e_dec < ENC_TOL
+        assert e_enc16 < ENC_TOL16 and e_dec16 < ENC_TOL16
+        x_in = x
     return out
 
 
@@ -108,6 +124,89 @@ def test_pipeline_five_levels_teacher_forced_and_fused_equals_stepwise(ctx, weig
             x = ctx.decode(t, relu)
         step = np.uint8(np.clip(x, 0, 1) * 255)
         assert np.array_equal(got, step), mode
+
+
+def test_config2_single_level_relu3_512_end_to_end(ctx, weights):
+    """BASELINE config 2 as stated: single level relu3_1, 512x512 content and style, alpha 0.8 (model.py:123-176: one
+    encoder -> wct -> decoder; covariances 256x256).  One level is well conditioned, so the final uint8 frame is
+    compared with the oracle's directly: against the fp32 oracle (the reference's arithmetic) and against the oracle
+    restated with this path's fp16 storage."""
+    targets = ['relu3_1']
+    c = synthetic_image(1000, 512, 512)
+    s = synthetic_image(2000, 512, 512)
+    _teacher_forced(ctx, weights, c, s, targets, 0.8, 'tf')
+    got = ctx.stylize(c, s, targets, alpha=0.8)
+    for name, want, min_psnr, max_lsb in (
+            ('fp32 oracle', oracle.stylize(c, s, weights, targets, alpha=0.8), 40.0, 12),
+            ('fp16-storage oracle', oracle.stylize(c, s, weights, targets, alpha=0.8, fp16_storage=True), 50.0, 3)):
+        d = np.abs(got.astype(int) - want.astype(int))
+        print('config 2 vs %s: psnr %.1f dB, max LSB %d, mean LSB %.4f, pixels off by > 1 LSB %.5f'
+              % (name, psnr(got, want), d.max(), d.mean(), (d > 1).mean()))
+        assert got.shape == want.shape == (512, 512, 3)
+        assert psnr(got, want) > min_psnr and d.max() <= max_lsb
+
+
+def test_pipeline_five_levels_teacher_forced_512(ctx, weights):
+    """BASELINE config 3 at its own size (512x512, five levels, alpha 0.8): every level's encoder, transform and
+    decoder on the oracle's own level inputs (the chained output itself is chaotic on random weights, see
+    test_pipeline_five_levels_teacher_forced_and_fused_equals_stepwise)."""
+    c = synthetic_image(1000, 512, 512)
+    s = synthetic_image(2000, 512, 512)
+    _teacher_forced(ctx, weights, c, s, RELU_TARGETS, 0.8, 'tf')
+
+
+@pytest.mark.parametrize('size', [(512, 512), (256, 384)])
+def test_encoder_decoder_stacks_full_size(ctx, weights, size):
+    """Layer stacks at the sizes the metric runs (the tall 32x16 tile path of the 64-channel layers, the 16x16 tile
+    path, pools fused into conv epilogues): all five encoder taps and all five decoders against the oracle."""
+    img = np.float32(synthetic_image(7, *size) / 255.)
+    want = oracle.encode(img, weights, RELU_TARGETS)
+    want16 = oracle.encode(img, weights, RELU_TARGETS, fp16_storage=True)
+    for relu in RELU_TARGETS:
+        got = ctx.encode(img, relu)
+        e, e16 = rel_err(got, want[relu]), rel_err(got, want16[relu])
+        feat = want[relu]
+        dec = ctx.decode(feat, relu)
+        d, d16 = rel_err(dec, oracle.decode(feat, weights, relu)), rel_err(dec, oracle.decode(feat, weights, relu, fp16_storage=True))
+        print('%s %s: encoder rel %.2e (fp16-storage oracle %.2e); decoder rel %.2e (fp16-storage oracle %.2e)'
+              % (size, relu, e, e16, d, d16))
+        assert got.shape == want[relu].shape and dec.shape == size + (3,)
+        assert e < ENC_TOL and d < ENC_TOL and e16 < ENC_TOL16 and d16 < ENC_TOL16
+
+
+def test_batch32_at_512_equals_single_pairs(ctx, weights):
+    """The bench configuration (32 resident pairs of 512x512 per call: batch strides, 32-bit buffer offsets, two
+    eigensolver groups): frames of the batched call equal the single-pair call bit for bit."""
+    B = 32
+    cs = np.stack([synthetic_image(1000 + i, 512, 512) for i in range(B)])
+    ss = np.stack([synthetic_image(2000 + i, 512, 512) for i in range(B)])
+    dc, ds, do = ctx.dev_alloc(cs.nbytes), ctx.dev_alloc(ss.nbytes), ctx.dev_alloc(cs.nbytes)
+    ctx.h2d(dc, cs); ctx.h2d(ds, ss)
+    ctx.stylize_batch_dev(dc, 512, 512, ds, 512, 512, B, RELU_TARGETS, 0.8, do)
+    ctx.sync()
+    outs = np.empty_like(cs)
+    ctx.d2h(outs, do)
+    for p in (dc, ds, do):
+        ctx.dev_free(p)
+    for i in (0, 13, 31):
+        assert np.array_equal(outs[i], ctx.stylize(cs[i], ss[i], RELU_TARGETS, alpha=0.8)), i
+    assert len({outs[i].tobytes() for i in range(B)}) == B
+
+
+def test_real_image_smoke_gilbert(ctx, weights):
+    """SURVEY 8d real-image smoke: crops of the reference's sample photo (samples/gilbert.jpg ->
+    tests/golden/gilbert_96.npz, made by oracle/make_golden.py) through three levels, against the oracle; smooth
+    natural-image statistics instead of blurred noise."""
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, 'gilbert_96.npz'))
+    c, s = z['content'], z['style']
+    assert c.shape == s.shape == (96, 96, 3) and c.dtype == np.uint8
+    targets = ['relu3_1', 'relu2_1', 'relu1_1']
+    want = _teacher_forced(ctx, weights, c, s, targets, 0.8, 'tf')
+    got = ctx.stylize(c, s, targets, alpha=0.8)
+    d = np.abs(got.astype(int) - want.astype(int))
+    print('gilbert 3-level: psnr %.1f dB, max LSB %d, mean LSB %.3f' % (psnr(got, want), d.max(), d.mean()))
+    assert psnr(got, want) > 30
 
 
 def test_pipeline_three_levels_end_to_end(ctx, weights):

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 import oracle
-from conftest import GOLDEN, rel_err, max_rel
+from conftest import GOLDEN, rel_err, max_rel, check_against_size_digest
 from wct_tf_amd.weights import (synthetic_weights, synthetic_features, synthetic_image,
                                 decoder_plan)
 
@@ -32,6 +32,31 @@ def test_wct_np_matches_reference_outputs():
         # same LAPACK, same op order: should agree to fp32 round-off
         assert rel_err(got, ref) < 1e-5, n
         assert max_rel(got, ref) < 1e-4, n
+
+
+def test_wct_np_matches_reference_on_defective_and_real_image_features():
+    """Dead channels, duplicated channels, 80 %-sparse maps, and features of the reference's sample photo
+    (tests/golden/gilbert_96.npz through the synthetic-weight encoder; relu4_1: 144 pixels < 512 channels)."""
+    z, names = _cases('wct_np_hard.npz')
+    assert len(names) == 5
+    for n in names:
+        got = oracle.wct_np(z[n + '/content'], z[n + '/style'], float(z[n + '/alpha']))
+        ref = z[n + '/out']
+        assert got.shape == ref.shape
+        assert rel_err(got, ref) < 1e-5 and max_rel(got, ref) < 1e-4, n
+
+
+def test_wct_np_matches_reference_at_config_sizes():
+    """The five WCT shapes of a 512x512 frame -- (512,1024) (512,4096) (256,16384) (128,65536) (64,262144) -- run
+    through the reference's own wct_np (oracle/make_golden.py); the fixture holds a digest of each output and the
+    inputs are rebuilt from their seeds (in_probe pins the rebuild)."""
+    from oracle.make_golden import SIZE_CASES, size_case_inputs, in_probe
+    z = np.load(os.path.join(GOLDEN, 'wct_np_sizes.npz'))
+    for case in SIZE_CASES:
+        fc, fs = size_case_inputs(case)
+        assert np.allclose(np.stack([in_probe(fc), in_probe(fs)]), z[case[0] + '/in_probe'], rtol=1e-6)
+        out = oracle.wct_np(fc, fs, case[4])
+        print(case[0], check_against_size_digest(z, case, out, 1e-5))
 
 
 def test_coral_matches_reference_outputs():

@@ -158,3 +158,17 @@ def synthetic_features(seed, c, h, w, decades=3.0, rank=None):
     if rank is None:
         f = np.maximum(f, 0)
     return f.reshape(1, h, w, c).astype(np.float32)
+
+
+def synthetic_features_exact(seed, c, h, w, decades=2.0):
+    """Same construction as synthetic_features, with the channel mixing done in float64 before the cast to
+    float32, so that two hosts with different BLAS kernels regenerate the same array to the last bit (up to rare
+    round-to-nearest ties): the large golden cases of tests/golden/wct_np_sizes.npz store only a digest of the
+    reference's output and rebuild their inputs from the seed."""
+    rng = np.random.default_rng(seed)
+    n = h * w
+    g = rng.standard_normal((n, c))
+    m = rng.standard_normal((c, c)) / np.sqrt(c)
+    scales = 10.0 ** rng.uniform(-decades / 2, decades / 2, c)
+    f = np.maximum(g @ m * scales + rng.uniform(0, 0.5, c), 0)
+    return f.reshape(1, h, w, c).astype(np.float32)
