@@ -31,7 +31,13 @@ extern "C" {
 typedef struct wct_ctx wct_ctx;
 
 enum wct_status { WCT_STATUS_OK = 0, WCT_STATUS_HIP = -1, WCT_STATUS_ARG = -2,
-                  WCT_STATUS_STATE = -3, WCT_STATUS_NOMEM = -4 };
+                  WCT_STATUS_STATE = -3, WCT_STATUS_NOMEM = -4,
+                  /* An eigendecomposition behind the call (the stand-in for tf.svd / np.linalg.svd, ops.py:53-65,110,123)
+                   * did not converge within its sweep budget (12 sweeps; 7-8 are typical at C = 512), or met NaN/Inf
+                   * in a covariance.  The outputs of the call ARE written (best effort, as LAPACK does with info > 0)
+                   * but must not be trusted; the reference's own worry at this spot is ops.py:57-65.  Reported by the
+                   * blocking calls themselves and, for wct_stylize_batch_dev (asynchronous), by the next wct_sync. */
+                  WCT_STATUS_NOCONV = -5 };
 
 /* transform semantics: wct_np (ops.py:92-140) or the live-graph wct_tf (ops.py:24-90) */
 enum wct_mode { WCT_NP = 0, WCT_TF = 1 };
@@ -50,7 +56,8 @@ enum wct_flags {
 int  wct_create(int device, wct_ctx** out);
 void wct_destroy(wct_ctx* ctx);
 const char* wct_last_error(void);
-int  wct_sync(wct_ctx* ctx);                       /* block until the ctx stream is idle */
+int  wct_sync(wct_ctx* ctx);                       /* block until the ctx stream is idle; WCT_STATUS_NOCONV if an
+                                                       eigensolve of the work just completed failed (see above) */
 int  wct_device_count(int* n);
 
 /* ---- weights: replace vgg_from_t7 (vgg_normalised.py:10-55) and the per-decoder
@@ -72,7 +79,9 @@ int wct_set_decoder(wct_ctx* ctx, int level, const float* const* w, const float*
  * default 1e-5; wct_tf: added to the covariance diagonal, default 1e-8); eps < 0 = default. */
 int wct_transform(wct_ctx* ctx, const float* content, int Nc, const float* style, int Ns,
                   int C, float alpha, int mode, float eps, float* out,
-                  int* sweeps_out /* [2] or NULL */);
+                  int* sweeps_out /* [2] (content, style) or NULL: Jacobi sweeps used, > 0 when converged;
+                                     -sweeps when still rotating after the sweep budget; <= -1000 for non-finite
+                                     input.  Any negative entry also makes the call return WCT_STATUS_NOCONV */);
 /* adain (ops.py:282-294), epsilon as in the reference signature */
 int wct_adain(wct_ctx* ctx, const float* content, int Nc, const float* style, int Ns,
               int C, float alpha, float epsilon, float* out);
@@ -87,7 +96,7 @@ int wct_set_style_swap(wct_ctx* ctx, float ss_alpha, int patch_size, int stride)
 /* symmetric eigendecomposition used in place of tf.svd / np.linalg.svd (ops.py:53-55,110,123):
  * A [nmat][C][C] in; evals [nmat][C], evecs [nmat][C][C] (columns) out. */
 int wct_eigh(wct_ctx* ctx, const float* A, int C, int nmat, float* evals, float* evecs,
-             int* sweeps_out /* [nmat] or NULL */);
+             int* sweeps_out /* [nmat] or NULL; same contract as wct_transform's */);
 /* Conv2DReflect (ops.py:17-19): x [H][W][Cin] fp32, w HWIO, y [Ho][Wo][Cout] fp32;
  * upsample!=0 applies UpSampling2D x2 first (model.py:293). fp16 operands, fp32 accumulate.
  * Cin and Cout must be multiples of 64 (every 3x3 layer of the path but conv1_1 / the output conv). */

@@ -75,6 +75,42 @@ def test_eigh_small_eigenvalues_keep_relative_accuracy(ctx):
     assert np.all(err <= 2e-4 * ref[big] + 1e-8 * ref.max()), (err / (2e-4 * ref[big] + 1e-8 * ref.max())).max()
 
 
+def test_eigensolver_failures_are_loud(ctx):
+    """a solve that runs out of sweeps used to return whatever A/V held, with rc 0.  Now: the call still
+    writes its outputs, returns WCT_STATUS_NOCONV (WCTNotConverged here), and sweeps_out carries -sweeps for the
+    matrices still rotating (<= -1000 for non-finite input) -- through wct_eigh, wct_transform and, for the
+    asynchronous batch entry point, through the next wct_sync.  The sweep budget is 12; WCT_JACOBI_MAX_SWEEPS (read
+    at every solve) lowers it so the path can be exercised: no symmetric matrix needs 12 cyclic sweeps."""
+    from wct_tf_amd._lib import WCTNotConverged
+    rng = np.random.default_rng(9)
+    a = _graded_spd(rng, 128, 3.0)
+    os.environ['WCT_JACOBI_MAX_SWEEPS'] = '2'
+    try:
+        with pytest.raises(WCTNotConverged, match='still rotating'):
+            ctx.eigh(np.stack([a, np.eye(128, dtype=np.float32)]))
+        assert list(ctx.last_sweeps) == [-2, 1]            # the identity is done after its first (idle) sweep
+        fc = synthetic_features(11, 64, 16, 16, 2.0)
+        fs = synthetic_features(12, 64, 16, 16, 2.0)
+        with pytest.raises(WCTNotConverged):
+            ctx.transform(fc.reshape(-1, 64), fs.reshape(-1, 64), 0.8, _lib.WCT_TF)
+        assert list(ctx.last_sweeps) == [-2, -2]
+    finally:
+        del os.environ['WCT_JACOBI_MAX_SWEEPS']
+    evals, _, sweeps = ctx.eigh(a, return_sweeps=True)     # the status does not stick
+    assert sweeps[0] > 2 and np.abs(np.sort(evals[0]) - np.linalg.eigvalsh(a.astype(np.float64))).max() < 2e-4 * np.abs(a).max() * 128
+    # non-finite input: one NaN in a covariance (e.g. an fp16 overflow upstream) must not come back as "converged"
+    bad = a.copy()
+    bad[5, 9] = bad[9, 5] = np.nan
+    with pytest.raises(WCTNotConverged, match='non-finite'):
+        ctx.eigh(np.stack([a, bad]))
+    assert ctx.last_sweeps[0] > 0 and ctx.last_sweeps[1] <= -1000
+    fc_bad = fc.copy()
+    fc_bad[0, 3, 3, 7] = np.inf
+    with pytest.raises(WCTNotConverged):
+        ctx.transform(fc_bad.reshape(-1, 64), fs.reshape(-1, 64), 0.8, _lib.WCT_NP)
+    _check_wct(ctx, fc, fs, 0.8, 'np')                     # and the context is usable afterwards
+
+
 def _check_wct(ctx, fc, fs, alpha, mode, tol=WCT_TOL):
     c = fc.shape[-1]
     want = (oracle.wct_np if mode == 'np' else oracle.wct_tf)(fc, fs, alpha)

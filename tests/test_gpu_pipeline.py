@@ -330,6 +330,31 @@ def test_full_size_properties_512(ctx, weights):
         assert err < 5e-3
 
 
+def test_pipeline_reports_failed_eigensolves_at_sync(ctx, weights):
+    """The asynchronous batch entry point cannot return the eigensolver's status itself: the next wct_sync does
+    (WCT_STATUS_NOCONV), and the blocking wct_stylize returns it directly; afterwards the context works as before."""
+    from wct_tf_amd._lib import WCTNotConverged
+    targets = ['relu3_1', 'relu1_1']
+    c, s = synthetic_image(1000, 64, 64), synthetic_image(2000, 64, 64)
+    good = ctx.stylize(c, s, targets, alpha=0.8)
+    os.environ['WCT_JACOBI_MAX_SWEEPS'] = '1'
+    try:
+        with pytest.raises(WCTNotConverged):
+            ctx.stylize(c, s, targets, alpha=0.8)
+        cs, ss = np.stack([c, c]), np.stack([s, s])
+        dc, ds, do = ctx.dev_alloc(cs.nbytes), ctx.dev_alloc(ss.nbytes), ctx.dev_alloc(cs.nbytes)
+        ctx.h2d(dc, cs); ctx.h2d(ds, ss)
+        ctx.stylize_batch_dev(dc, 64, 64, ds, 64, 64, 2, targets, 0.8, do)        # enqueues; no status yet
+        with pytest.raises(WCTNotConverged):
+            ctx.sync()
+        ctx.sync()                                                                 # reported once
+        for p in (dc, ds, do):
+            ctx.dev_free(p)
+    finally:
+        del os.environ['WCT_JACOBI_MAX_SWEEPS']
+    assert np.array_equal(ctx.stylize(c, s, targets, alpha=0.8), good)
+
+
 def test_swap5_pipeline(ctx, weights):
     """--swap5: style-swap at relu5_1 (priority over adain), WCT below.  The fused call must equal the
     GPU ops chained by hand; the relu5_1 op is checked against the oracle on the oracle's features."""

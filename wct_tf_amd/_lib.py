@@ -68,6 +68,14 @@ class WCTHipError(RuntimeError):
     pass
 
 
+class WCTNotConverged(WCTHipError):
+    """WCT_STATUS_NOCONV: an eigendecomposition behind the call ran out of sweeps or met NaN/Inf (the reference's
+    np.linalg.svd raises LinAlgError at the same spot, ops.py:110,123).  Outputs were written but are unreliable."""
+
+
+STATUS_NOCONV = -5
+
+
 def load():
     """Load libwct_hip.so and declare every prototype.  Raises if it is missing."""
     global _lib
@@ -86,7 +94,8 @@ def load():
 
 def check(rc):
     if rc != 0:
-        raise WCTHipError('libwct_hip error %d: %s' % (rc, load().wct_last_error().decode()))
+        cls = WCTNotConverged if rc == STATUS_NOCONV else WCTHipError
+        raise cls('libwct_hip error %d: %s' % (rc, load().wct_last_error().decode()))
 
 
 def fptr(a):

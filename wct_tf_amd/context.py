@@ -89,6 +89,7 @@ class Context(object):
             raise ValueError('expected [N][C] feature matrices with equal C')
         out = np.empty_like(c)
         sweeps = (C.c_int * 2)()
+        self.last_sweeps = sweeps            # negative entries: that eigensolve failed (the call raises WCTNotConverged)
         check(self.lib.wct_transform(self.h, fptr(c), c.shape[0], fptr(s), s.shape[0], c.shape[1],
                                      float(alpha), int(mode), float(eps), fptr(out), sweeps))
         return (out, list(sweeps)) if return_sweeps else out
@@ -121,6 +122,7 @@ class Context(object):
         evals = np.empty((n, c), np.float32)
         evecs = np.empty((n, c, c), np.float32)
         sweeps = (C.c_int * n)()
+        self.last_sweeps = sweeps
         check(self.lib.wct_eigh(self.h, fptr(a), c, n, fptr(evals), fptr(evecs), sweeps))
         return (evals, evecs, list(sweeps)) if return_sweeps else (evals, evecs)
 

@@ -69,6 +69,8 @@ struct wct_ctx {
   DevBuf train_ws;
   Decoder dec[6];
   DevBuf act[2], feat_c, feat_s[6], img_c, img_s, img_t[2], wct_out, wct_ws, stage[4];
+  int* eig_fail = nullptr;         // pinned host memory mapped into the device, [4 stream groups][2]: eigenproblems that did
+  int* eig_fail_dev = nullptr;     // not converge / had non-finite input -- bumped by jacobi_finalize_kernel
   float ss_alpha = 0.6f;           // style-swap settings (stylize.py:34-37 defaults)
   int ss_patch = 3, ss_stride = 1;
   bool prof = false;
@@ -149,6 +151,14 @@ extern "C" int wct_create(int device, wct_ctx** out) {
     delete c;
     return WCT_ERR_HIP;
   }
+  if (ok) ok = hipHostMalloc((void**)&c->eig_fail, 8 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
+               hipHostGetDevicePointer((void**)&c->eig_fail_dev, c->eig_fail, 0) == hipSuccess;
+  if (!ok) {
+    wct_set_error("hipHostMalloc (mapped status words) failed");
+    delete c;
+    return WCT_ERR_HIP;
+  }
+  for (int i = 0; i < 8; ++i) c->eig_fail[i] = 0;
   if (const char* e = getenv("WCT_EIG_GROUPS")) { int n = atoi(e); c->nside = n < 1 ? 0 : (n > 4 ? 3 : n - 1); }
   *out = c;
   return WCT_OK;
@@ -186,16 +196,29 @@ extern "C" void wct_destroy(wct_ctx* c) {
   for (auto& b : c->feat_s) if (b.p) hipFree(b.p);
   for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto& e : c->free_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (c->eig_fail) hipHostFree(c->eig_fail);
   hipEventDestroy(c->ev_fork);
   for (int i = 0; i < 3; ++i) { hipStreamSynchronize(c->side[i]); hipEventDestroy(c->ev_join[i]); hipStreamDestroy(c->side[i]); }
   hipStreamDestroy(c->stream);
   delete c;
 }
 
+// After a stream sync: did any eigensolve since the last check fail?  The frames / features of the call are still
+// written (best effort, like LAPACK's "did not converge" info > 0), but the status is loud: WCT_STATUS_NOCONV.
+static int eig_status(wct_ctx* c) {
+  int n_open = 0, n_nan = 0;
+  for (int g = 0; g < 4; ++g) { n_open += c->eig_fail[2 * g]; n_nan += c->eig_fail[2 * g + 1]; }
+  if (!n_open && !n_nan) return WCT_OK;
+  for (int i = 0; i < 8; ++i) c->eig_fail[i] = 0;
+  wct_set_error("eigensolver: %d covariance matri%s still rotating after the sweep budget, %d with non-finite entries "
+                "(NaN/Inf features?); the outputs of this call are not reliable", n_open, n_open == 1 ? "x" : "ces", n_nan);
+  return WCT_ERR_NOCONV;
+}
+
 extern "C" int wct_sync(wct_ctx* c) {
   ARG_CHECK(c != nullptr);
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return WCT_OK;
+  return eig_status(c);
 }
 
 extern "C" int wct_dev_alloc(wct_ctx* c, size_t bytes, void** out) {
@@ -534,14 +557,14 @@ static int run_transform(wct_ctx* c, const float* fc, int Nc, const float* fs, i
   const int mode = (flags & WCT_FLAG_MODE_NP) ? WCT_MODE_NP : WCT_MODE_TF;
   {
     ProfScope ps(c, 4, (double)P * 2.0 * C * C * ((double)Nc + Ns), (double)P * 2.0 * ((double)Nc + Ns) * C * 4);
-    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, 0, nullptr, nullptr, shared));
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, 0, nullptr, nullptr, shared, c->eig_fail_dev));
   }
   {
     ProfScope ps(c, 5, 0, 0);
-    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_EIG, c->stream, c->side, c->nside, c->ev_fork, c->ev_join, shared));
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_EIG, c->stream, c->side, c->nside, c->ev_fork, c->ev_join, shared, c->eig_fail_dev));
   }
   ProfScope ps(c, 6, (double)P * (2.0 * C * C * Nc + 6.0 * C * C * C), (double)P * Nc * C * (4 + (out16 ? 2 : 0) + (out32 ? 4 : 0)));
-  return launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_APPLY, c->stream, nullptr, 0, nullptr, nullptr, shared);
+  return launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_APPLY, c->stream, nullptr, 0, nullptr, nullptr, shared, c->eig_fail_dev);
 }
 
 // ---------------------------------------------------------------------------
@@ -572,7 +595,7 @@ extern "C" int wct_transform(wct_ctx* c, const float* content, int Nc, const flo
                     nullptr, (float*)c->stage[2].p, (int*)c->stage[3].p));
   TRY(fetch(c, out, c->stage[2].p, (size_t)Nc * C * 4));
   if (sweeps_out) TRY(fetch(c, sweeps_out, c->stage[3].p, 2 * sizeof(int)));
-  return WCT_OK;
+  return eig_status(c);
 }
 
 extern "C" int wct_adain(wct_ctx* c, const float* content, int Nc, const float* style, int Ns, int C,
@@ -606,8 +629,9 @@ extern "C" int wct_style_swap(wct_ctx* c, const float* content, int hc, int wc, 
   ARG_CHECK(patch_size >= 1 && stride >= 1 && hc >= patch_size && wc >= patch_size && hs >= patch_size && ws >= patch_size);
   TRY(ensure(c, c->wct_ws, style_swap_workspace_bytes(C, hc, wc, hs, ws, patch_size, stride)));
   TRY(launch_style_swap((float*)dc, hc, wc, (float*)ds, hs, ws, C, alpha, patch_size, stride, eps, nullptr,
-                        (float*)c->stage[2].p, c->wct_ws.p, c->wct_ws.cap, c->stream));
-  return fetch(c, out, c->stage[2].p, (size_t)hc * wc * C * 4);
+                        (float*)c->stage[2].p, c->wct_ws.p, c->wct_ws.cap, c->stream, c->eig_fail_dev));
+  TRY(fetch(c, out, c->stage[2].p, (size_t)hc * wc * C * 4));
+  return eig_status(c);
 }
 
 __global__ void extract_diag_kernel(const float* A, float* d, int C) {
@@ -627,13 +651,13 @@ extern "C" int wct_eigh(wct_ctx* c, const float* A, int C, int nmat, float* eval
   int* sw = (int*)((char*)c->stage[2].p + (size_t)nmat * C * 4);
   {
     ProfScope ps(c, 5, 0, 0);
-    TRY(launch_jacobi_eigh((float*)dA, (float*)c->stage[1].p, C, nmat, c->wct_ws.p, c->wct_ws.cap, sw, c->stream));
+    TRY(launch_jacobi_eigh((float*)dA, (float*)c->stage[1].p, C, nmat, c->wct_ws.p, c->wct_ws.cap, sw, c->eig_fail_dev, c->stream));
   }
   hipLaunchKernelGGL(extract_diag_kernel, dim3(cdiv(C, 256), nmat), dim3(256), 0, c->stream, (float*)dA, (float*)c->stage[2].p, C);
   TRY(fetch(c, evals, c->stage[2].p, (size_t)nmat * C * 4));
   TRY(fetch(c, evecs, c->stage[1].p, mb));
   if (sweeps_out) TRY(fetch(c, sweeps_out, sw, nmat * sizeof(int)));
-  return WCT_OK;
+  return eig_status(c);
 }
 
 extern "C" int wct_conv3x3(wct_ctx* c, const float* x, int H, int W, int Cin, const float* w_hwio, const float* bias,
@@ -816,7 +840,7 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
         TRY(launch_style_swap((float*)c->feat_c.p + (size_t)b * h * w * C, h, w,
                               (float*)c->feat_s[l].p + (size_t)(shared ? 0 : b) * hs * ws * C, hs, ws, C, c->ss_alpha, c->ss_patch,
                               c->ss_stride, -1.f, (half_t*)c->wct_out.p + (size_t)b * h * w * C, nullptr,
-                              c->wct_ws.p, c->wct_ws.cap, c->stream));
+                              c->wct_ws.p, c->wct_ws.cap, c->stream, c->eig_fail_dev));
     } else
     TRY(run_transform(c, (float*)c->feat_c.p, h * w, (float*)c->feat_s[l].p, hs * ws, C, B, alpha, flags, -1.f,
                       (half_t*)c->wct_out.p, nullptr, nullptr));
@@ -846,7 +870,8 @@ extern "C" int wct_stylize(wct_ctx* c, const uint8_t* content, int Hc, int Wc, c
   TRY(ensure(c, c->stage[2], (size_t)Ho * Wo * 3));
   TRY(wct_stylize_batch_dev(c, (uint8_t*)dc, Hc, Wc, (uint8_t*)ds, Hs, Ws, 1, levels, n_levels, alpha, flags,
                             (uint8_t*)c->stage[2].p));
-  return fetch(c, out, c->stage[2].p, (size_t)Ho * Wo * 3);
+  TRY(fetch(c, out, c->stage[2].p, (size_t)Ho * Wo * 3));
+  return eig_status(c);
 }
 
 // ---------------------------------------------------------------------------

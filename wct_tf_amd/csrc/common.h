@@ -15,6 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WCT_ERR_ARG -2
 #define WCT_ERR_STATE -3
 #define WCT_ERR_NOMEM -4
+#define WCT_ERR_NOCONV -5
 
 void wct_set_error(const char* fmt, ...);
 
@@ -113,22 +114,26 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
                const hipStream_t* side /* optional extra streams: the eigenproblems are split over 1+nside */,
                int nside, hipEvent_t ev_fork, const hipEvent_t* ev_join,
                int shared_style /* style holds ONE feature map used by all P pairs: its statistics and
-                                   eigensystem are computed once */);
+                                   eigensystem are computed once */,
+               int* eig_fail /* device-visible status words [4 stream groups][2] (not converged, non-finite), bumped by the
+                                eigensolver, or null */);
 enum { WCT_STAGE_COV = 1, WCT_STAGE_EIG = 2, WCT_STAGE_APPLY = 4, WCT_STAGE_ALL = 7 };
 int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P,
                  float alpha, float eps, half_t* out16, float* out32,
                  void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style);
 // Symmetric eigensolver (batched): A [nmat][C][C] is overwritten (diag -> eigenvalues),
 // V [nmat][C][C] gets eigenvectors in columns.  C multiple of 32, 32 <= C <= 1024.
+// sweeps_done_dev[m]: sweeps used (> 0) if matrix m converged, -sweeps if it was still rotating when the sweep
+// budget ran out, <= -1000 for non-finite input; eig_fail as in launch_wct.
 int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace,
-                       size_t workspace_bytes, int* sweeps_done_dev, hipStream_t s);
+                       size_t workspace_bytes, int* sweeps_done_dev, int* eig_fail, hipStream_t s);
 size_t jacobi_workspace_bytes(int C, int nmat);
 
 // Style-swap at relu5_1 (ops.py:145-278): one pair, content [hc*wc][C], style [hs*ws][C] fp32.
 size_t style_swap_workspace_bytes(int C, int hc, int wc, int hs, int ws, int patch, int stride);
 int launch_style_swap(const float* content, int hc, int wc, const float* style, int hs, int ws, int C,
                       float alpha, int patch, int stride, float eps, half_t* out16, float* out32,
-                      void* workspace, size_t workspace_bytes, hipStream_t s);
+                      void* workspace, size_t workspace_bytes, hipStream_t s, int* eig_fail);
 
 // ---- train.hip ------------------------------------------------------------
 int launch_im2col_act(const half_t* x, float* col, int B, int H, int W, int C, int upsample, hipStream_t s);

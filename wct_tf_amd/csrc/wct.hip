@@ -11,8 +11,6 @@
 //                     blend and re-centring folded into M and b)
 #include "common.h"
 #include <stdlib.h>
-#include <map>
-#include <string>
 #include <type_traits>
 
 // ---------------------------------------------------------------------------
@@ -679,39 +677,148 @@ __device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned cha
   return 0;                                                          // NP is even: the result is back in image 0
 }
 
+// The cross sweep with ONE wave carrying the rotation parameters ("pivot wave"), the default since round 2.
+// In jacobi_cross_sets every thread derives rotation(l) itself (~35 instructions with three transcendentals on a
+// dependent chain, 32x redundant) and the owners mirror the pivots into the D/O arrays.  Here:
+//   * threads are numbered along the diagonals of the (k, l) grid: k = t % NP, d = t / NP, l = k + d + 1 (mod NP), so the
+//     NP threads (k, k+1) that own S[p_k][q_k'] -- the element pair k annihilates in the NEXT set -- are the first NP
+//     lanes of wave 0;
+//   * those lanes keep pair k's pivot block (pp, qq, pq) in registers: pp and qq follow in closed form from the
+//     rotation they computed for this set (c^2 pp - 2cs pq + s^2 qq, ...), the q diagonal of pair k+1 arrives by one
+//     lane shuffle, pq is their own freshly rotated element; they derive the next rotation and publish (c, s) in a
+//     ping-pong LDS array; every other wave reads (c_l, s_l), (c_k, s_k) -- two 8-byte loads -- and only rotates;
+//   * within a set every element of the {S, Q} image is read and written by exactly one thread, so the image is
+//     updated in place (one image instead of two); with PITCH = N the 8-byte accesses of a diagonal are conflict-free.
+// Per set a bulk wave issues ~45 instructions instead of ~100, and the dependent chain of a set is the pivot wave's.
+template <int N>
+__device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned char* csb, int t, float& my_off) {
+  constexpr int NP = N / 2, ROWB = N * 8;                            // bytes per image row
+  constexpr int CSB = NP * 8, DUMMY = 2 * CSB;                       // csb layout: CS[2][NP] float2 (c, s), dummy float2
+  const int k = t & (NP - 1), d = t / NP;
+  const int l = (k + d + 1) & (NP - 1);
+  const bool pwave = __builtin_amdgcn_readfirstlane(t >> 6) == 0;    // wave-uniform: the wave holding the lanes (k, k+1)
+  const bool piv = d == 0;
+  const int nb_lane = (t & 63 & ~(NP - 1)) | ((k + 1) & (NP - 1));   // lane of pair k+1
+  float ppk = 0.f, qqk = 0.f, pqk = 0.f, ck = 1.f, sk = 0.f;         // pair k's pivot block and rotation (pivot wave only)
+  if (pwave) {
+    __builtin_amdgcn_s_setprio(2);                                   // the chain of a set runs through this wave
+    const f32x2* SQ = reinterpret_cast<const f32x2*>(sq);
+    ppk = SQ[k * N + k][0]; qqk = SQ[(NP + k) * N + NP + k][0]; pqk = SQ[k * N + NP + k][0];   // set 0 pairs k with NP + k
+    float off;
+    jacobi_rotation(ppk, qqk, pqk, ck, sk, off);
+    if (piv) my_off = fmaxf(my_off, off);
+    f32x2 r; r[0] = ck; r[1] = sk;
+    *reinterpret_cast<f32x2*>(csb + (piv ? k * 8 : DUMMY)) = r;
+  }
+  __syncthreads();
+  const int row_pk = k * ROWB, col_pl = l * 8;
+  const int a_pp = row_pk + col_pl;
+  int qk = NP + k, ql = NP + l;                                      // q index of set s: NP + ((j + s) & (NP - 1))
+  const int cs_l = l * 8, cs_k = k * 8;
+  const int cs_w0 = piv ? k * 8 : DUMMY, cs_w1 = piv ? CSB + k * 8 : DUMMY;   // the dummy slot absorbs the lanes that own no pair
+  auto ld2 = [&](const unsigned char* base, int off) { return *reinterpret_cast<const f32x2*>(base + off); };
+  auto body = [&](auto CURC) {
+    constexpr int CUR = decltype(CURC)::value, NX = CUR ^ 1;
+    const f32x2 rl = ld2(csb + CUR * CSB, cs_l), rk = ld2(csb + CUR * CSB, cs_k);
+    const int qlb = ql * 8, qkb = qk * ROWB;
+    const int a_pq = row_pk + qlb, a_qp = qkb + col_pl, a_qq = qkb + qlb;
+    const f32x2 app = ld2(sq, a_pp), apq = ld2(sq, a_pq), aqp = ld2(sq, a_qp), aqq = ld2(sq, a_qq);
+    const float cl = rl[0], sl = rl[1], ckk = rk[0], skk = rk[1];
+    // columns (pair l) on S and Q, then rows (pair k) on S
+    const float ypp = cl * app[0] - sl * apq[0], ypq = sl * app[0] + cl * apq[0];
+    const float yqp = cl * aqp[0] - sl * aqq[0], yqq = sl * aqp[0] + cl * aqq[0];
+    f32x2 npp, npq, nqp, nqq;
+    npp[1] = cl * app[1] - sl * apq[1];  npq[1] = sl * app[1] + cl * apq[1];
+    nqp[1] = cl * aqp[1] - sl * aqq[1];  nqq[1] = sl * aqp[1] + cl * aqq[1];
+    npp[0] = ckk * ypp - skk * yqp;  npq[0] = ckk * ypq - skk * yqq;
+    nqp[0] = skk * ypp + ckk * yqp;  nqq[0] = skk * ypq + ckk * yqq;
+    if (pwave) {
+      // pair k after this set's rotation (closed form from registers), the next set's partner diagonal from the
+      // lane of pair k+1, the next pivot element from this thread's own block
+      const float c2 = ck * ck, s2 = sk * sk, cs2 = 2.f * ck * sk;
+      const float ppn = c2 * ppk - cs2 * pqk + s2 * qqk;
+      const float qqn = s2 * ppk + cs2 * pqk + c2 * qqk;
+      const float qq_next = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb_lane * 4, __builtin_bit_cast(int, qqn)));
+      ppk = ppn; qqk = qq_next; pqk = npq[0];
+      float off;
+      jacobi_rotation(ppk, qqk, pqk, ck, sk, off);
+      if (piv) my_off = fmaxf(my_off, off);
+      f32x2 r; r[0] = ck; r[1] = sk;
+      *reinterpret_cast<f32x2*>(csb + (NX ? cs_w1 : cs_w0)) = r;
+    }
+    *reinterpret_cast<f32x2*>(sq + a_pp) = npp;  *reinterpret_cast<f32x2*>(sq + a_pq) = npq;
+    *reinterpret_cast<f32x2*>(sq + a_qp) = nqp;  *reinterpret_cast<f32x2*>(sq + a_qq) = nqq;
+    qk = NP | ((qk + 1) & (NP - 1));
+    ql = NP | ((ql + 1) & (NP - 1));
+    __syncthreads();
+  };
+#pragma unroll 1
+  for (int s = 0; s < NP; s += 2) {
+    body(std::integral_constant<int, 0>{});
+    body(std::integral_constant<int, 1>{});
+  }
+}
+
 // measured (tools/probe/jacobi_probe.hip): more blocks per thread is SLOWER (N = 64: 1761 / 1930 / 2412 / 3643 cycles per
 // set for KB = 1 / 2 / 4 / 8; with two blocks resident per CU 2910 vs 3010) -- fewer waves hide less LDS latency -- so KB = 1
 template <int M2> struct JacobiCfg { static constexpr int KB = 1; static constexpr int NT = (M2 / 2) * (M2 / 2) / KB; };
 
 // One outer step: pair problem of blocks (bi, bj) -> rotation matrix Q (M2 x M2) in Qbuf.
-template <int M2>
+// PW: the cross steps run jacobi_cross_sets_pw on an in-place image of pitch M2 (LDS: jacobi_diag_lds<M2>(step, pw)).
+// A non-finite element anywhere in the pair problem makes the block report an infinite off-diagonal measure, which
+// jacobi_check_kernel turns into done = 2 ("failed: non-finite input") instead of a silent "converged".
+template <int M2, bool PW>
 __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A, float* Qbuf, JacobiState* st, int C, int step) {
-  constexpr int B = M2 / 2, PITCH = M2 + 1, NT = JacobiCfg<M2>::NT, KB = JacobiCfg<M2>::KB;
+  constexpr int B = M2 / 2, NT = JacobiCfg<M2>::NT, KB = JacobiCfg<M2>::KB;
   const int m = blockIdx.y, g = blockIdx.x;
   if (st[m].done) return;
   extern __shared__ __attribute__((aligned(16))) float jsm[];
-  f32x2* SQ = reinterpret_cast<f32x2*>(jsm);         // [2][M2][PITCH]
+  f32x2* SQ = reinterpret_cast<f32x2*>(jsm);
   const int tid = threadIdx.x;
   const int nblk = C / B, npair = nblk / 2;
   int bi, bj;
   block_pair(g, step, nblk, bi, bj);
   float* Am = A + (size_t)m * C * C;
-  for (int e = tid; e < M2 * M2; e += NT) {
-    const int r = e / M2, c = e % M2;
-    f32x2 v;
-    v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
-    v[1] = r == c ? 1.f : 0.f;
-    SQ[r * PITCH + c] = v;
-  }
-  float my_off = 0.f;
-  __syncthreads();
-  float* DO = jsm + 4 * M2 * PITCH;                   // after the two float2 images
-  const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, my_off)
-                           : jacobi_cross_sets<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(DO), tid, my_off);
   float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
-  for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
+  float my_off = 0.f;
+  bool finite = true;
+  if (PW && step >= 0) {
+    for (int e = tid; e < M2 * M2; e += NT) {
+      const int r = e / M2, c = e % M2;
+      f32x2 v;
+      v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
+      v[1] = r == c ? 1.f : 0.f;
+      finite &= fabsf(v[0]) <= 3.0e38f;
+      SQ[e] = v;
+    }
+    __syncthreads();
+    jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, my_off);
+    for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[e][1];
+  } else {
+    constexpr int PITCH = M2 + 1;                       // [2][M2][PITCH] ping-pong images
+    for (int e = tid; e < M2 * M2; e += NT) {
+      const int r = e / M2, c = e % M2;
+      f32x2 v;
+      v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
+      v[1] = r == c ? 1.f : 0.f;
+      finite &= fabsf(v[0]) <= 3.0e38f;
+      SQ[r * PITCH + c] = v;
+    }
+    __syncthreads();
+    float* DO = jsm + 4 * M2 * PITCH;                   // after the two float2 images
+    const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, my_off)
+                             : jacobi_cross_sets<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(DO), tid, my_off);
+    for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
+  }
+  if (!finite) my_off = __builtin_inff();
   for (int o = 32; o > 0; o >>= 1) my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
   if ((tid & 63) == 0) atomicMax(&st[m].offmax, __float_as_uint(my_off));
+}
+
+template <int M2>
+static size_t jacobi_diag_lds(int step, bool pw) {
+  if (pw && step >= 0) return (size_t)M2 * M2 * sizeof(f32x2) + (size_t)(M2 + 2) * sizeof(f32x2);   // image, CS[2][M2/2], dummy
+  return (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2) + 4 * M2 * sizeof(float);                         // images, D[2][M2], O[2][M2/2], dummy[M2]
 }
 
 // acc (32x32 MFMA C/D layout) -> the 16 B operands of the next 32x32x2 MFMA chain, in
@@ -843,19 +950,40 @@ __global__ void jacobi_init_kernel(float* V, JacobiState* st, int C, int mat0, i
   if (blockIdx.x == 0 && threadIdx.x == 0) { st[m].offmax = 0u; st[m].done = skip ? 1 : 0; st[m].sweeps = 0; st[m].pad = 0; }
 }
 
+// done: 0 = still rotating, 1 = converged, 2 = failed (a non-finite element reached a pair problem)
 __global__ void jacobi_check_kernel(JacobiState* st, int nmat, float conv_tol) {
   const int m = threadIdx.x;
   if (m >= nmat || st[m].done) return;
   st[m].sweeps += 1;
-  if (__uint_as_float(st[m].offmax) < conv_tol) st[m].done = 1;
+  const unsigned bits = st[m].offmax;                   // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
+  if (bits >= 0x7f800000u) st[m].done = 2;
+  else if (__uint_as_float(bits) < conv_tol) st[m].done = 1;
   st[m].offmax = 0u;
 }
 
-__global__ void jacobi_export_sweeps_kernel(const JacobiState* st, int* out, int nmat) {
-  if ((int)threadIdx.x < nmat) out[threadIdx.x] = st[threadIdx.x].sweeps;
+// End of a solve: sweeps_out[m] = sweeps used if matrix m converged, -sweeps if it was still rotating after the last
+// allowed sweep, -1000 - sweeps for non-finite input; fail[0] += matrices not converged, fail[1] += non-finite ones.
+// fail: this group's slot of the caller's status words (host memory mapped into the device, one slot per stream
+// group so that plain read-modify-writes of one thread suffice), read by the caller after its next stream sync --
+// a failed solve is never silently dropped.
+__global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, int nmat, volatile int* fail) {
+  const int m = threadIdx.x;
+  const int d = m < nmat ? st[m].done : 1;
+  if (m < nmat && sweeps_out) sweeps_out[m] = d == 1 ? st[m].sweeps : (d == 2 ? -1000 - st[m].sweeps : -st[m].sweeps);
+  const int n_open = __builtin_popcountll(__ballot(d == 0)), n_nan = __builtin_popcountll(__ballot(d == 2));
+  if (m == 0 && fail) {
+    if (n_open) fail[0] = fail[0] + n_open;
+    if (n_nan) fail[1] = fail[1] + n_nan;
+  }
 }
 
 constexpr int JACOBI_MAX_SWEEPS = 12;
+// WCT_JACOBI_MAX_SWEEPS (read at every solve): lowers the sweep budget so that the non-convergence path can be tested
+static int jacobi_max_sweeps() {
+  const char* e = getenv("WCT_JACOBI_MAX_SWEEPS");
+  const int n = e ? atoi(e) : JACOBI_MAX_SWEEPS;
+  return n < 1 ? 1 : (n > 30 ? 30 : n);
+}
 
 size_t jacobi_workspace_bytes(int C, int nmat) {
   return (size_t)nmat * C * 64 * sizeof(float) + 256 + (size_t)nmat * sizeof(JacobiState);   // Q tiles: (C/M2) * M2*M2 <= C*64
@@ -866,123 +994,99 @@ size_t jacobi_workspace_bytes(int C, int nmat) {
 struct JacobiGroup {
   float* A; float* V; int nmat; float* Qbuf; JacobiState* st; hipStream_t stream; int* sweeps_out;
   int mat0, shared_style;      // position in a WCT batch (skip_style_mat); 0, 0 for a plain batch
+  int* fail;                   // device view of this group's slot [2] of the caller's status words, or null
 };
 
-static JacobiState* jacobi_host_flags() {
-  static thread_local JacobiState* h = nullptr;   // pinned, 4 groups x 64 matrices; one per host thread (= per ctx user)
-  if (!h && hipHostMalloc((void**)&h, 4 * 64 * sizeof(JacobiState)) != hipSuccess) h = nullptr;
-  return h;
+// per host thread (= per ctx user): pinned copies of the groups' convergence flags and one event per group
+struct JacobiHost { JacobiState* flags; hipEvent_t ev[4]; };
+static JacobiHost* jacobi_host() {
+  static thread_local JacobiHost h = {nullptr, {nullptr, nullptr, nullptr, nullptr}};
+  if (!h.flags) {
+    if (hipHostMalloc((void**)&h.flags, 4 * 64 * sizeof(JacobiState)) != hipSuccess) { h.flags = nullptr; return nullptr; }
+    for (int g = 0; g < 4; ++g)
+      if (hipEventCreateWithFlags(&h.ev[g], hipEventDisableTiming) != hipSuccess) { hipHostFree(h.flags); h.flags = nullptr; return nullptr; }
+  }
+  return &h;
 }
 
-// One sweep = (C/B + 1) x 2 kernels per group; at ~4-5 us of host time per launch several groups
-// would be launch-bound, so a sweep is captured once into a hipGraph (cross-stream capture: the side
-// streams fork from and join back to the first group's stream) and replayed once per sweep.
-struct SweepGraph { hipGraphExec_t exec; };
-static std::map<std::string, SweepGraph>& sweep_graph_cache() {
-  static std::map<std::string, SweepGraph> c;
-  return c;
+// the pivot-wave cross sweep (jacobi_cross_sets_pw) is the default; WCT_JACOBI_PW=0 selects the round-1 kernel
+static bool jacobi_use_pw() {
+  static const int pw = getenv("WCT_JACOBI_PW") ? atoi(getenv("WCT_JACOBI_PW")) : 1;
+  return pw != 0;
 }
 
+// steps [step_begin, step_end) of one sweep: step -1 rotates the pairs inside each block, steps 0.. the cross pairs
+// of every block pair -- each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
 template <int M2>
-static void jacobi_enqueue_sweep(const JacobiGroup* grp, int ngrp, int C) {
+static void jacobi_enqueue_steps(const JacobiGroup* grp, int ngrp, int C, int step_begin, int step_end) {
   constexpr int B = M2 / 2;
   const int nblk = C / B, npair = nblk / 2;
-  const size_t lds = (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2) + 4 * M2 * sizeof(float);     // images, D[2][M2], O[2][M2/2], dummy[M2]
-  // step -1 rotates the pairs inside each block, steps 0.. the cross pairs of every block pair:
-  // each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
-  for (int step = -1; step < nblk - 1; ++step)
+  const bool pw = jacobi_use_pw();
+  for (int step = step_begin; step < step_end; ++step)
     for (int g = 0; g < ngrp; ++g) {
       const JacobiGroup& G = grp[g];
-      hipLaunchKernelGGL((jacobi_diag_kernel<M2>), dim3(npair, G.nmat), dim3(JacobiCfg<M2>::NT), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
+      const size_t lds = jacobi_diag_lds<M2>(step, pw);
+      if (pw) hipLaunchKernelGGL((jacobi_diag_kernel<M2, true>), dim3(npair, G.nmat), dim3(JacobiCfg<M2>::NT), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
+      else hipLaunchKernelGGL((jacobi_diag_kernel<M2, false>), dim3(npair, G.nmat), dim3(JacobiCfg<M2>::NT), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
       hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3((M2 == 64 ? npair * (npair + 1) / 2 : npair * npair) + npair * npair, G.nmat),
                          dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
     }
-  static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
-  for (int g = 0; g < ngrp; ++g)
-    hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].nmat, conv_tol);
 }
 
-template <int M2>
-static int jacobi_sweep_graph(const JacobiGroup* grp, int ngrp, int C, hipGraphExec_t* out) {
-  std::string key((const char*)grp, sizeof(JacobiGroup) * ngrp);
-  key.append((const char*)&C, sizeof(C));
-  const int m2 = M2;
-  key.append((const char*)&m2, sizeof(m2));
-  auto& cache = sweep_graph_cache();
-  auto it = cache.find(key);
-  if (it != cache.end()) { *out = it->second.exec; return WCT_OK; }
-  hipStream_t main = grp[0].stream;
-  hipEvent_t fork, join[4];
-  HIP_TRY(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-  for (int g = 1; g < ngrp; ++g) HIP_TRY(hipEventCreateWithFlags(&join[g], hipEventDisableTiming));
-  HIP_TRY(hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal));
-  HIP_TRY(hipEventRecord(fork, main));
-  for (int g = 1; g < ngrp; ++g) HIP_TRY(hipStreamWaitEvent(grp[g].stream, fork, 0));
-  jacobi_enqueue_sweep<M2>(grp, ngrp, C);
-  for (int g = 1; g < ngrp; ++g) {
-    HIP_TRY(hipEventRecord(join[g], grp[g].stream));
-    HIP_TRY(hipStreamWaitEvent(main, join[g], 0));
-  }
-  hipGraph_t graph;
-  HIP_TRY(hipStreamEndCapture(main, &graph));
-  SweepGraph sg;
-  HIP_TRY(hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0));
-  HIP_TRY(hipGraphDestroy(graph));
-  cache[key] = sg;
-  *out = sg.exec;
-  return WCT_OK;
-}
-
+// Sweeps until every matrix of every group is done or the sweep budget is spent.  The `done` flag turns the launches
+// of a finished matrix into no-ops on the device; to stop LAUNCHING, the host reads the flags back -- asynchronously:
+// the copy of sweep k's flags is waited for only after the first half of sweep k+1 has been enqueued, so the GPU
+// never idles behind the host (round 1 synchronised the streams after every sweep from the 4th on).  When the
+// flags say "all done" the half sweep already in flight is a run of no-op launches (~2 us apiece).
 template <int M2>
 static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
-  // measured on MI355X (ROCm 7.2): replaying the captured multi-stream sweep is SLOWER than eager launches
-  // (4 groups: 29.0 vs 22.4 ms/step), so the graph path is opt-in (WCT_JACOBI_GRAPH=1)
-  static const int use_graph = getenv("WCT_JACOBI_GRAPH") ? atoi(getenv("WCT_JACOBI_GRAPH")) : 0;
-  JacobiState* host = jacobi_host_flags();
-  hipStream_t main = grp[0].stream;
+  constexpr int B = M2 / 2;
+  const int nblk = C / B;
+  const int half = -1 + nblk / 2;                 // steps [-1, half) | [half, nblk - 1)
+  const int max_sweeps = jacobi_max_sweeps();
+  static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
+  JacobiHost* host = jacobi_host();
   for (int g = 0; g < ngrp; ++g)
     hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].V, grp[g].st, C,
                        grp[g].mat0, grp[g].shared_style);
-  hipGraphExec_t exec = nullptr;
-  if (use_graph) {
-    // the graph forks from / joins to the main stream: the side streams' init kernels must be ordered first
-    for (int g = 1; g < ngrp; ++g) HIP_TRY(hipStreamSynchronize(grp[g].stream));
-    int rc = jacobi_sweep_graph<M2>(grp, ngrp, C, &exec);
-    if (rc) return rc;
-  }
-  for (int sweep = 0; sweep < JACOBI_MAX_SWEEPS; ++sweep) {
-    if (exec) HIP_TRY(hipGraphLaunch(exec, main));
-    else jacobi_enqueue_sweep<M2>(grp, ngrp, C);
-    // From the 4th sweep on, read the convergence flags back and stop launching once every matrix is
-    // done (the `done` flag alone would turn the remaining launches into no-ops, at ~3 us apiece).
-    if (host && sweep >= 3 && sweep + 1 < JACOBI_MAX_SWEEPS) {
+  bool pending = false;                           // a copy of the previous sweep's flags is in flight
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    jacobi_enqueue_steps<M2>(grp, ngrp, C, -1, half);
+    if (pending) {
       bool all = true;
       for (int g = 0; g < ngrp; ++g) {
-        hipStream_t sg = exec ? main : grp[g].stream;
-        HIP_TRY(hipMemcpyAsync(host + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, sg));
+        HIP_TRY(hipEventSynchronize(host->ev[g]));
+        for (int m = 0; m < grp[g].nmat; ++m) all = all && host->flags[g * 64 + m].done != 0;
       }
-      for (int g = 0; g < ngrp; ++g) {
-        HIP_TRY(hipStreamSynchronize(exec ? main : grp[g].stream));
-        for (int m = 0; m < grp[g].nmat; ++m) all = all && host[g * 64 + m].done;
-      }
+      pending = false;
       if (all) break;
+    }
+    jacobi_enqueue_steps<M2>(grp, ngrp, C, half, nblk - 1);
+    for (int g = 0; g < ngrp; ++g)
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].nmat, conv_tol);
+    if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
+      for (int g = 0; g < ngrp; ++g) {
+        HIP_TRY(hipMemcpyAsync(host->flags + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, grp[g].stream));
+        HIP_TRY(hipEventRecord(host->ev[g], grp[g].stream));
+      }
+      pending = true;
     }
   }
   for (int g = 0; g < ngrp; ++g)
-    if (grp[g].sweeps_out)
-      hipLaunchKernelGGL(jacobi_export_sweeps_kernel, dim3(1), dim3(64), 0, exec ? main : grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat);
+    if (grp[g].sweeps_out || grp[g].fail)
+      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, grp[g].fail);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
 
 static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
-                             int* sweeps_out, hipStream_t s) {
+                             int* sweeps_out, int* fail, hipStream_t s) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
   ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
   const size_t qbytes = (size_t)nmat * C * 64 * sizeof(float);
   G->A = A; G->V = V; G->nmat = nmat; G->Qbuf = reinterpret_cast<float*>(workspace);
   G->st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
-  G->stream = s; G->sweeps_out = sweeps_out;
+  G->stream = s; G->sweeps_out = sweeps_out; G->fail = fail;
   G->mat0 = 0; G->shared_style = 0;
   return WCT_OK;
 }
@@ -997,9 +1101,9 @@ static int jacobi_dispatch(JacobiGroup* grp, int ngrp, int C) {
 }
 
 int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
-                       int* sweeps_done_dev, hipStream_t s) {
+                       int* sweeps_done_dev, int* eig_fail, hipStream_t s) {
   JacobiGroup G;
-  int rc = jacobi_make_group(&G, A, V, C, nmat, workspace, workspace_bytes, sweeps_done_dev, s);
+  int rc = jacobi_make_group(&G, A, V, C, nmat, workspace, workspace_bytes, sweeps_done_dev, eig_fail, s);
   if (rc) return rc;
   return jacobi_dispatch(&G, 1, C);
 }
@@ -1310,7 +1414,7 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
                half_t* out16, float* out32, void* workspace, size_t workspace_bytes, int* sweeps_dev,
                int stages, hipStream_t s, const hipStream_t* side, int nside, hipEvent_t ev_fork,
-               const hipEvent_t* ev_join, int shared_style) {
+               const hipEvent_t* ev_join, int shared_style, int* eig_fail) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && Nc >= 2 && Ns >= 2 && P >= 1 && P <= 32);
   ARG_CHECK(mode == WCT_MODE_NP || mode == WCT_MODE_TF);
   // the covariance kernel addresses one feature map through a buffer resource with 32-bit byte offsets
@@ -1365,7 +1469,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
         hipStream_t sg = g == 0 ? s : side[g - 1];
         if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ev_fork, 0));
         if ((rc = jacobi_make_group(&grp[g], w.A + (size_t)m0 * cc, w.V + (size_t)m0 * cc, C, n, (char*)w.jacobi_ws + off,
-                                    bytes, sweeps_dev ? sweeps_dev + m0 : nullptr, sg))) return rc;
+                                    bytes, sweeps_dev ? sweeps_dev + m0 : nullptr, eig_fail ? eig_fail + 2 * g : nullptr, sg))) return rc;
         grp[g].mat0 = m0; grp[g].shared_style = shared_style;
         off += bytes; m0 += n;
       }
@@ -1376,7 +1480,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       }
     } else {
       JacobiGroup G;
-      if ((rc = jacobi_make_group(&G, w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, s))) return rc;
+      if ((rc = jacobi_make_group(&G, w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, eig_fail, s))) return rc;
       G.shared_style = shared_style;
       if ((rc = jacobi_dispatch(&G, 1, C))) return rc;
     }
@@ -1605,7 +1709,7 @@ static inline unsigned ew_grid(size_t n) { size_t g = (n + 255) / 256; return (u
 
 int launch_style_swap(const float* content, int hc, int wc, const float* style, int hs, int ws, int C,
                       float alpha, int patch, int stride, float eps, half_t* out16, float* out32,
-                      void* workspace, size_t workspace_bytes, hipStream_t s) {
+                      void* workspace, size_t workspace_bytes, hipStream_t s, int* eig_fail) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && patch >= 1 && stride >= 1);
   ARG_CHECK(hc >= patch && wc >= patch && hs >= patch && ws >= patch);
   const int ho = (hc - patch) / stride + 1, wo = (wc - patch) / stride + 1;
@@ -1624,7 +1728,7 @@ int launch_style_swap(const float* content, int hc, int wc, const float* style, 
   int rc;
   // statistics, covariances (+eps I), eigendecompositions: the same stages as wct_tf
   if ((rc = launch_wct(content, Nc, style, Ns, C, 1, alpha, WCT_MODE_TF, eps, nullptr, nullptr, workspace, wct_bytes,
-                       nullptr, WCT_STAGE_COV | WCT_STAGE_EIG, s, nullptr, 0, nullptr, nullptr, 0))) return rc;
+                       nullptr, WCT_STAGE_COV | WCT_STAGE_EIG, s, nullptr, 0, nullptr, nullptr, 0, eig_fail))) return rc;
   const size_t cc = (size_t)C * C;
   float *d_cw = sw.d3, *d_sw = sw.d3 + C, *d_sc = sw.d3 + 2 * C;
   hipLaunchKernelGGL(swap_gain_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, w.A, d_cw, d_sw, d_sc, C);
