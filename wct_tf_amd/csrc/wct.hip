@@ -462,10 +462,13 @@ __global__ void cov_finish_kernel(const float* partial, const float* scale, floa
 //   A per-matrix `done` flag turns later launches into no-ops.
 // ---------------------------------------------------------------------------
 struct JacobiState {
-  unsigned int offmax;   // max |a_pq|/sqrt(a_pp a_qq) seen this sweep (float bits)
-  int done;
+  unsigned int offmax;   // max |a_pq|/sqrt(a_pp a_qq) over the pairs rotated this sweep (float bits)
+  int done;              // 0 rotating, 1 converged, 2 failed: non-finite input
   int sweeps;
-  int pad;
+  unsigned int offsig;   // the same maximum over the SIGNIFICANT pairs only (a diagonal above `floor`)
+  float floor;           // 32 eps max|a_ii| of the input: diagonals below it are rounding noise of a matrix of this norm
+  unsigned int last_sig; // offsig of the last completed sweep (what jacobi_finalize_kernel judges)
+  int pad[2];
 };
 
 __device__ __forceinline__ int rr_idx(int pos, int step, int n) {
@@ -496,7 +499,10 @@ constexpr float JACOBI_FLOOR = 1e-6f;      // both diagonals below this: the pai
 // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (a_qq - a_pp) / (2 a_pq), written as
 // t = +-|a_pq| / (|tau| + sqrt(tau^2 + a_pq^2)), tau = (a_qq - a_pp)/2: three transcendentals
 // on the dependent chain (sqrt, rcp, rsq) and no division by a_pq.
-__device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq, float& c, float& s, float& off) {
+// `sig` = the same measure if the pair is significant (its larger diagonal is above the matrix' noise floor), else 0:
+// pairs inside the numerical null space keep relative off-diagonals of O(1) for ever (every update regenerates
+// rounding noise there) without mattering for f(A); they are still rotated, but they do not count as "not converged".
+__device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq, float floor_m, float& c, float& s, float& off, float& sig) {
   const float den2 = fabsf(app * aqq);
   const float aapq = fabsf(apq);
   const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
@@ -516,6 +522,7 @@ __device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq,
   c = rot ? r : 1.f;
   s = rot ? r * t : 0.f;
   off = rot ? rel : 0.f;
+  sig = big > floor_m ? off : 0.f;
 }
 
 // Rotation sets on an N x N symmetric pair problem (N = 32 or 64: blocks I = 0..N/2-1 and
@@ -546,7 +553,7 @@ __device__ __forceinline__ void sweep_pair(int j, int s, int& p, int& q) {
 // KB = 2x2 blocks per thread (rows k, k + NP/KB, ...; one column pair l): rotation(l) is derived once
 // per thread and reused for its KB blocks.
 template <int MODE, int N, int KB>
-__device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& my_off) {
+__device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float floor_m, float& my_off, float& my_sig) {
   constexpr int NP = N / 2, PITCH = N + 1, IMG = N * PITCH, KS = NP / KB;
   constexpr int NSETS = MODE == SWEEP_CROSS ? NP : NP - 1;
   const int kq = t / NP, l = t % NP;
@@ -575,9 +582,10 @@ __device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& m
       app[i] = C0[pk[i] * PITCH + pl]; apq[i] = C0[pk[i] * PITCH + ql];
       aqp[i] = C0[qk[i] * PITCH + pl]; aqq[i] = C0[qk[i] * PITCH + ql];
     }
-    float cl, sl, offl;
-    jacobi_rotation(lpp, lqq, lpq, cl, sl, offl);
+    float cl, sl, offl, sigl;
+    jacobi_rotation(lpp, lqq, lpq, floor_m, cl, sl, offl, sigl);
     my_off = fmaxf(my_off, offl);
+    my_sig = fmaxf(my_sig, sigl);
     const int nx = cur ^ 1;
 #pragma unroll
     for (int i = 0; i < KB; ++i) {
@@ -615,7 +623,7 @@ __device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float& m
 // (hipcc's packed-f32 form of the same arithmetic spent 9 v_mov per set on operand assembly).
 // 149 -> ~100 instructions per set.
 template <int N>
-__device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned char* dob, int t, float& my_off) {
+__device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned char* dob, int t, float floor_m, float& my_off, float& my_sig) {
   constexpr int NP = N / 2, PITCH = N + 1, IMGB = N * PITCH * 8;     // bytes per {S,Q} image
   constexpr int DB = N * 4, OB = NP * 4;                             // bytes per D / O image
   constexpr int O_OFF = 2 * DB, DUMMY = 2 * DB + 2 * OB;             // dob layout: D[2][N], O[2][NP], dummy[N]
@@ -647,9 +655,10 @@ __device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned cha
     const int a_pq = row_pk + qlb, a_qp = qkb + col_pl, a_qq = qkb + qlb;
     const float lpp = ldf(dob + CUR * DB, d_l), lqq = ldf(dob + CUR * DB, ql * 4), lpq = ldf(dob + CUR * OB, o_l);
     const f32x2 app = ld2(C0, a_pp), apq = ld2(C0, a_pq), aqp = ld2(C0, a_qp), aqq = ld2(C0, a_qq);
-    float cl, sl, offl;
-    jacobi_rotation(lpp, lqq, lpq, cl, sl, offl);
+    float cl, sl, offl, sigl;
+    jacobi_rotation(lpp, lqq, lpq, floor_m, cl, sl, offl, sigl);
     my_off = fmaxf(my_off, offl);
+    my_sig = fmaxf(my_sig, sigl);
     const float ck = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm, __builtin_bit_cast(int, cl)));
     const float sk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm, __builtin_bit_cast(int, sl)));
     // columns (pair l) on S and Q, then rows (pair k) on S
@@ -691,7 +700,7 @@ __device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned cha
 //     updated in place (one image instead of two); with PITCH = N the 8-byte accesses of a diagonal are conflict-free.
 // Per set a bulk wave issues ~45 instructions instead of ~100, and the dependent chain of a set is the pivot wave's.
 template <int N>
-__device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned char* csb, int t, float& my_off) {
+__device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned char* csb, int t, float floor_m, float& my_off, float& my_sig) {
   constexpr int NP = N / 2, ROWB = N * 8;                            // bytes per image row
   constexpr int CSB = NP * 8, DUMMY = 2 * CSB;                       // csb layout: CS[2][NP] float2 (c, s), dummy float2
   const int k = t & (NP - 1), d = t / NP;
@@ -704,9 +713,9 @@ __device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned
     __builtin_amdgcn_s_setprio(2);                                   // the chain of a set runs through this wave
     const f32x2* SQ = reinterpret_cast<const f32x2*>(sq);
     ppk = SQ[k * N + k][0]; qqk = SQ[(NP + k) * N + NP + k][0]; pqk = SQ[k * N + NP + k][0];   // set 0 pairs k with NP + k
-    float off;
-    jacobi_rotation(ppk, qqk, pqk, ck, sk, off);
-    if (piv) my_off = fmaxf(my_off, off);
+    float off, sig;
+    jacobi_rotation(ppk, qqk, pqk, floor_m, ck, sk, off, sig);
+    if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
     f32x2 r; r[0] = ck; r[1] = sk;
     *reinterpret_cast<f32x2*>(csb + (piv ? k * 8 : DUMMY)) = r;
   }
@@ -740,9 +749,9 @@ __device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned
       const float qqn = s2 * ppk + cs2 * pqk + c2 * qqk;
       const float qq_next = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb_lane * 4, __builtin_bit_cast(int, qqn)));
       ppk = ppn; qqk = qq_next; pqk = npq[0];
-      float off;
-      jacobi_rotation(ppk, qqk, pqk, ck, sk, off);
-      if (piv) my_off = fmaxf(my_off, off);
+      float off, sig;
+      jacobi_rotation(ppk, qqk, pqk, floor_m, ck, sk, off, sig);
+      if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
       f32x2 r; r[0] = ck; r[1] = sk;
       *reinterpret_cast<f32x2*>(csb + (NX ? cs_w1 : cs_w0)) = r;
     }
@@ -780,7 +789,8 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
   block_pair(g, step, nblk, bi, bj);
   float* Am = A + (size_t)m * C * C;
   float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
-  float my_off = 0.f;
+  float my_off = 0.f, my_sig = 0.f;
+  const float floor_m = st[m].floor;
   bool finite = true;
   if (PW && step >= 0) {
     for (int e = tid; e < M2 * M2; e += NT) {
@@ -792,7 +802,7 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
       SQ[e] = v;
     }
     __syncthreads();
-    jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, my_off);
+    jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig);
     for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[e][1];
   } else {
     constexpr int PITCH = M2 + 1;                       // [2][M2][PITCH] ping-pong images
@@ -806,13 +816,19 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
     }
     __syncthreads();
     float* DO = jsm + 4 * M2 * PITCH;                   // after the two float2 images
-    const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, my_off)
-                             : jacobi_cross_sets<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(DO), tid, my_off);
+    const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, floor_m, my_off, my_sig)
+                             : jacobi_cross_sets<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(DO), tid, floor_m, my_off, my_sig);
     for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
   }
   if (!finite) my_off = __builtin_inff();
-  for (int o = 32; o > 0; o >>= 1) my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
-  if ((tid & 63) == 0) atomicMax(&st[m].offmax, __float_as_uint(my_off));
+  for (int o = 32; o > 0; o >>= 1) {
+    my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
+    my_sig = fmaxf(my_sig, __shfl_xor(my_sig, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    if (my_off > 0.f) atomicMax(&st[m].offmax, __float_as_uint(my_off));
+    if (my_sig > 0.f) atomicMax(&st[m].offsig, __float_as_uint(my_sig));
+  }
 }
 
 template <int M2>
@@ -940,14 +956,28 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
 }
 
 // mat0 = index of the group's first matrix in the 2P batch; skipped style matrices start out `done`
-__global__ void jacobi_init_kernel(float* V, JacobiState* st, int C, int mat0, int shared_style) {
+__global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float* V, JacobiState* st, int C, int mat0, int shared_style) {
+  __shared__ float red[4];
   const int m = blockIdx.y;
   const bool skip = skip_style_mat(mat0 + m, shared_style);
   const size_t cc = (size_t)C * C;
   if (!skip)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x)
       V[(size_t)m * cc + i] = (i / C == i % C) ? 1.f : 0.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { st[m].offmax = 0u; st[m].done = skip ? 1 : 0; st[m].sweeps = 0; st[m].pad = 0; }
+  if (blockIdx.x == 0) {
+    float mx = 0.f;                          // NaN diagonals drop out of fmaxf; the pair kernels flag them
+    if (!skip) for (int i = threadIdx.x; i < C; i += 256) mx = fmaxf(mx, fabsf(A[(size_t)m * cc + (size_t)i * C + i]));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      JacobiState z;
+      z.offmax = 0u; z.done = skip ? 1 : 0; z.sweeps = 0; z.offsig = 0u;
+      z.floor = fminf(32.f * 5.9604645e-8f * mx, 3.0e38f); z.last_sig = 0u; z.pad[0] = z.pad[1] = 0;
+      st[m] = z;
+    }
+  }
 }
 
 // done: 0 = still rotating, 1 = converged, 2 = failed (a non-finite element reached a pair problem)
@@ -958,17 +988,23 @@ __global__ void jacobi_check_kernel(JacobiState* st, int nmat, float conv_tol) {
   const unsigned bits = st[m].offmax;                   // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
   if (bits >= 0x7f800000u) st[m].done = 2;
   else if (__uint_as_float(bits) < conv_tol) st[m].done = 1;
+  st[m].last_sig = st[m].offsig;
   st[m].offmax = 0u;
+  st[m].offsig = 0u;
 }
 
-// End of a solve: sweeps_out[m] = sweeps used if matrix m converged, -sweeps if it was still rotating after the last
-// allowed sweep, -1000 - sweeps for non-finite input; fail[0] += matrices not converged, fail[1] += non-finite ones.
+// End of a solve.  A matrix still rotating after the last allowed sweep has FAILED only if its last sweep still saw a
+// significant pair above the tolerance; noise-level pairs alone (numerical null space of a rank-deficient covariance:
+// N < C pixels, dead or duplicated channels) never settle and do not matter.
+// sweeps_out[m] = sweeps used if matrix m is good, -sweeps if it failed to converge, -1000 - sweeps for non-finite
+// input; fail[0] += matrices not converged, fail[1] += non-finite ones.
 // fail: this group's slot of the caller's status words (host memory mapped into the device, one slot per stream
 // group so that plain read-modify-writes of one thread suffice), read by the caller after its next stream sync --
 // a failed solve is never silently dropped.
-__global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, int nmat, volatile int* fail) {
+__global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, int nmat, float conv_tol, volatile int* fail) {
   const int m = threadIdx.x;
-  const int d = m < nmat ? st[m].done : 1;
+  int d = m < nmat ? st[m].done : 1;
+  if (d == 0 && __uint_as_float(st[m].last_sig) < conv_tol) d = 1;
   if (m < nmat && sweeps_out) sweeps_out[m] = d == 1 ? st[m].sweeps : (d == 2 ? -1000 - st[m].sweeps : -st[m].sweeps);
   const int n_open = __builtin_popcountll(__ballot(d == 0)), n_nan = __builtin_popcountll(__ballot(d == 2));
   if (m == 0 && fail) {
@@ -1047,7 +1083,7 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
   JacobiHost* host = jacobi_host();
   for (int g = 0; g < ngrp; ++g)
-    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].V, grp[g].st, C,
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].V, grp[g].st, C,
                        grp[g].mat0, grp[g].shared_style);
   bool pending = false;                           // a copy of the previous sweep's flags is in flight
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
@@ -1074,7 +1110,7 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   }
   for (int g = 0; g < ngrp; ++g)
     if (grp[g].sweeps_out || grp[g].fail)
-      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, grp[g].fail);
+      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, conv_tol, grp[g].fail);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
