@@ -12,9 +12,15 @@ pytestmark = pytest.mark.gpu
 # fp16 activations through up to 13 stacked convs, against the fp32 oracle: the storage rounding itself is 7.6e-3 at
 # relu5_1 of a 512x512 image (oracle fp32 vs oracle with fp16 storage, measured)
 ENC_TOL = 1e-2
-# against the oracle restated with the same storage precision (oracle.encode/decode(fp16_storage=True)): what is left
-# is the fp32 accumulation order and the few fp16 roundings it flips
-ENC_TOL16 = 1e-3
+# Stack tolerances by level (relative L2), ~2.5x the values measured on MI355X at 512x512 (in brackets).  The random
+# zero-sum filters amplify a perturbation ~2x per conv (test_oracle.py::test_five_level_chain_is_chaotic_on_random_weights),
+# so a deep stack cannot be held to the per-layer figure; the per-layer figure itself (2e-4, every layer at its real size
+# on the oracle's own inputs) is test_every_conv_layer_at_full_size_teacher_forced.
+#   *_32: against the fp32 oracle;  *_16: against the oracle restated with this path's fp16 storage
+ENC_TOL_32 = {1: 1e-5, 2: 1.5e-3, 3: 3e-3, 4: 8e-3, 5: 1.5e-2}      # [4.9e-7, 5.9e-4, 1.1e-3, -, 7.6e-3]
+ENC_TOL_16 = {1: 1e-5, 2: 2e-4, 3: 1e-3, 4: 5e-3, 5: 8e-3}          # [4.9e-7, 6.5e-5, 3.8e-4, -, 3.9e-3]
+DEC_TOL_32 = {1: 4e-4, 2: 8e-4, 3: 1.5e-3, 4: 5e-3, 5: 8e-3}        # [1.5e-4, 3.0e-4, 5.5e-4, -, 3.3e-3]
+DEC_TOL_16 = {1: 2e-5, 2: 8e-5, 3: 4e-4, 4: 2e-3, 5: 4e-3}          # [4.2e-6, 2.3e-5, 1.4e-4, -, 1.7e-3]
 
 
 @pytest.fixture(scope='module')
@@ -82,9 +88,10 @@ def _teacher_forced(ctx, weights, content, style, targets, alpha, mode):
         e_dec, e_dec16 = rel_err(got_x, x), rel_err(got_x, oracle.decode(t, weights, relu, fp16_storage=True))
         print('%s %s: encoder rel %.2e (fp16-storage oracle %.2e)  transform rel %.2e  decoder rel %.2e (fp16-storage oracle %.2e)'
               % (relu, fc.shape, e_enc, e_enc16, e, e_dec, e_dec16))
+        lv = int(relu[4])
         assert e < 1e-3
-        assert e_enc < ENC_TOL and e_dec < ENC_TOL
-        assert e_enc16 < ENC_TOL16 and e_dec16 < ENC_TOL16
+        assert e_enc < ENC_TOL_32[lv] and e_dec < DEC_TOL_32[lv]
+        assert e_enc16 < ENC_TOL_16[lv] and e_dec16 < DEC_TOL_16[lv]
         x_in = x
     return out
 
@@ -170,8 +177,58 @@ def test_encoder_decoder_stacks_full_size(ctx, weights, size):
         d, d16 = rel_err(dec, oracle.decode(feat, weights, relu)), rel_err(dec, oracle.decode(feat, weights, relu, fp16_storage=True))
         print('%s %s: encoder rel %.2e (fp16-storage oracle %.2e); decoder rel %.2e (fp16-storage oracle %.2e)'
               % (size, relu, e, e16, d, d16))
+        lv = int(relu[4])
         assert got.shape == want[relu].shape and dec.shape == size + (3,)
-        assert e < ENC_TOL and d < ENC_TOL and e16 < ENC_TOL16 and d16 < ENC_TOL16
+        assert e < ENC_TOL_32[lv] and d < DEC_TOL_32[lv] and e16 < ENC_TOL_16[lv] and d16 < DEC_TOL_16[lv]
+
+
+def test_every_conv_layer_at_full_size_teacher_forced(ctx, weights):
+    """Every 3x3 layer of the 512x512 path at its real size -- the 12 encoder convs behind conv1_1 and the 12
+    decoder-5 convs ahead of the output conv (all (Cin, Cout, H) combinations of SURVEY 8a's table, both tile
+    configurations, the folded upsample) -- each on the ORACLE's input for that layer (fp16-rounded, as stored), so no
+    error is inherited: what is measured is one layer's arithmetic.  Tolerance 2e-4 (fp32 accumulation order)."""
+    from oracle.net_oracle import ENCODER_LAYERS, decoder_layers
+    h16 = lambda a: np.asarray(a, np.float16).astype(np.float32)    # noqa: E731
+    img = np.float32(synthetic_image(7, 512, 512) / 255.)
+    enc = weights['encoder']
+    x = oracle.conv1x1(img, *enc['preprocess'])
+    worst = 0.0
+    for layer in ENCODER_LAYERS:
+        if layer[0] == 'P':
+            x = oracle.maxpool2x2_same(x)
+            continue
+        name = layer[1]
+        w, b = enc[name]
+        if name != 'conv1_1':
+            x = h16(x)
+            want = oracle.conv3x3_reflect(x, h16(w), b, relu=True)
+            got = ctx.conv3x3(x, w, b, relu=True)
+            e = rel_err(got, want)
+            worst = max(worst, e)
+            print('%s %s -> %d: rel %.2e  max %.2e' % (name, x.shape, w.shape[3], e, max_rel(got, want)))
+            assert e < 2e-4 and max_rel(got, want) < 2e-3, name
+            x = want
+        else:
+            x = oracle.conv3x3_reflect(x, w, b, relu=True)
+    params = iter(weights['decoder']['relu5_1'])
+    up = False
+    x = h16(x)
+    for kind, cin, cout, relu in decoder_layers('relu5_1'):
+        if kind == 'U':
+            up = True
+            continue
+        w, b = next(params)
+        if cout == 3:
+            break
+        xin = oracle.upsample2x_nearest(x) if up else x
+        want = oracle.conv3x3_reflect(xin, h16(w), b, relu=relu)
+        got = ctx.conv3x3(x, w, b, relu=relu, upsample=up)
+        e = rel_err(got, want)
+        worst = max(worst, e)
+        print('dec5 %s%s -> %d: rel %.2e  max %.2e' % (x.shape, ' x2' if up else '', cout, e, max_rel(got, want)))
+        assert e < 2e-4 and max_rel(got, want) < 2e-3
+        x, up = h16(want), False
+    print('worst layer: %.2e' % worst)
 
 
 def test_batch32_at_512_equals_single_pairs(ctx, weights):

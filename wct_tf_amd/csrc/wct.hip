@@ -466,10 +466,13 @@ struct JacobiState {
   int done;              // 0 rotating, 1 converged, 2 failed: non-finite input
   int sweeps;
   unsigned int offsig;   // the same maximum over the SIGNIFICANT pairs only (a diagonal above `floor`)
-  float floor;           // 32 eps max|a_ii| of the input: diagonals below it are rounding noise of a matrix of this norm
+  float floor;           // 1e-5 max|a_ii| of the previous sweep (-> 1e-5 lambda_max): diagonals below it belong to the
+                         // numerical null space of a matrix of this norm (~170 eps ||A||)
   unsigned int last_sig; // offsig of the last completed sweep (what jacobi_finalize_kernel judges)
-  int pad[2];
+  unsigned int dmax;     // max |a_ii| seen by this sweep's pair problems (float bits)
+  int pad;
 };
+constexpr float JACOBI_SIG_FLOOR = 1e-5f;
 
 __device__ __forceinline__ int rr_idx(int pos, int step, int n) {
   // circle method: position 0 is fixed, the other n-1 rotate
@@ -829,6 +832,12 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
     if (my_off > 0.f) atomicMax(&st[m].offmax, __float_as_uint(my_off));
     if (my_sig > 0.f) atomicMax(&st[m].offsig, __float_as_uint(my_sig));
   }
+  if (tid < 64) {                               // largest diagonal of the rotated pair problem -> next sweep's floor
+    float dm = 0.f;
+    for (int i = tid; i < M2; i += 64) dm = fmaxf(dm, fabsf(Am[(size_t)pair_index<B>(i, bi, bj) * C + pair_index<B>(i, bi, bj)]));
+    for (int o = 32; o > 0; o >>= 1) dm = fmaxf(dm, __shfl_xor(dm, o, 64));
+    if (tid == 0 && dm < 3.0e38f) atomicMax(&st[m].dmax, __float_as_uint(dm));
+  }
 }
 
 template <int M2>
@@ -974,7 +983,7 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
       mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
       JacobiState z;
       z.offmax = 0u; z.done = skip ? 1 : 0; z.sweeps = 0; z.offsig = 0u;
-      z.floor = fminf(32.f * 5.9604645e-8f * mx, 3.0e38f); z.last_sig = 0u; z.pad[0] = z.pad[1] = 0;
+      z.floor = JACOBI_SIG_FLOOR * fminf(mx, 3.0e38f); z.last_sig = 0u; z.dmax = 0u; z.pad = 0;
       st[m] = z;
     }
   }
@@ -989,8 +998,10 @@ __global__ void jacobi_check_kernel(JacobiState* st, int nmat, float conv_tol) {
   if (bits >= 0x7f800000u) st[m].done = 2;
   else if (__uint_as_float(bits) < conv_tol) st[m].done = 1;
   st[m].last_sig = st[m].offsig;
+  st[m].floor = fmaxf(st[m].floor, JACOBI_SIG_FLOOR * __uint_as_float(st[m].dmax));
   st[m].offmax = 0u;
   st[m].offsig = 0u;
+  st[m].dmax = 0u;
 }
 
 // End of a solve.  A matrix still rotating after the last allowed sweep has FAILED only if its last sweep still saw a
