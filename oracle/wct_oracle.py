@@ -60,11 +60,12 @@ def wct_np(content, style, alpha=0.6, eps=1e-5, keep=None):
     return np.float32(_unflatten(blended, cshape))
 
 
-def wct_tf(content, style, alpha, eps=1e-8, keep=None):
+def wct_tf(content, style, alpha, eps=1e-8, keep=None, dtype=np.float32):
     """Whiten-colour transform, TensorFlow-graph semantics of ops.py:24-90.
 
     `keep` = (kc, ks): test-only override of the kept counts, see wct_np (the reference keeps
-    singular values > 1e-5, ops.py:68-69).
+    singular values > 1e-5, ops.py:68-69).  `dtype`: test-only, np.float64 re-runs the same graph
+    in double precision to measure how much of the float32 result is rounding noise.
 
     * eps*I added to both covariances (ops.py:45,50)
     * keep singular values > 1e-5 (ops.py:68-69)
@@ -72,31 +73,32 @@ def wct_tf(content, style, alpha, eps=1e-8, keep=None):
     * blend alpha*fcs + (1-alpha)*(fc + mc) : content mean restored (ops.py:83)
     Computed in float32 like the TF graph.
     """
-    fc_full, cshape = _flatten_chw(np.asarray(content, np.float32))
-    fs_full, _ = _flatten_chw(np.asarray(style, np.float32))
+    f = dtype
+    fc_full, cshape = _flatten_chw(np.asarray(content, f))
+    fs_full, _ = _flatten_chw(np.asarray(style, f))
     c = fc_full.shape[0]
     nc = fc_full.shape[1]
     ns = fs_full.shape[1]
-    eye = np.eye(c, dtype=np.float32)
+    eye = np.eye(c, dtype=f)
 
     mc = fc_full.mean(axis=1, keepdims=True)
     fc = fc_full - mc
-    cov_c = np.dot(fc, fc.T) / np.float32(nc - 1.0) + eye * np.float32(eps)
+    cov_c = np.dot(fc, fc.T) / f(nc - 1.0) + eye * f(eps)
     ms = fs_full.mean(axis=1, keepdims=True)
     fs = fs_full - ms
-    cov_s = np.dot(fs, fs.T) / np.float32(ns - 1.0) + eye * np.float32(eps)
+    cov_s = np.dot(fs, fs.T) / f(ns - 1.0) + eye * f(eps)
 
     uc, sc, _ = np.linalg.svd(cov_c)
     us, ss, _ = np.linalg.svd(cov_s)
     kc = int((sc > 1e-5).sum()) if keep is None else int(keep[0])
     ks = int((ss > 1e-5).sum()) if keep is None else int(keep[1])
 
-    dc = np.diag(sc[:kc] ** np.float32(-0.5))
+    dc = np.diag(sc[:kc] ** f(-0.5))
     whitened = uc[:, :kc].dot(dc).dot(uc[:, :kc].T).dot(fc)
-    ds = np.diag(ss[:ks] ** np.float32(0.5))
+    ds = np.diag(ss[:ks] ** f(0.5))
     colored = us[:, :ks].dot(ds).dot(us[:, :ks].T).dot(whitened) + ms
 
-    blended = np.float32(alpha) * colored + np.float32(1 - alpha) * (fc + mc)
+    blended = f(alpha) * colored + f(1 - alpha) * (fc + mc)
     return np.float32(_unflatten(blended, cshape))
 
 

@@ -20,7 +20,7 @@ from wct_tf_amd import _lib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
-STATS = {'wct_cases': 0, 'wct_near_cutoff': 0}
+STATS = {'wct_cases': 0, 'wct_near_cutoff': 0, 'wct_indeterminate': 0}
 
 
 @pytest.fixture(scope='module')
@@ -70,19 +70,36 @@ def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_s
         assert rel_err(got, want) < 1e-3, (c, nc, ns, alpha, mode, log_scale)
         return
     STATS['wct_near_cutoff'] += 1
+    shaped = (fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c))
+    # kept counts inside the band: all of them when the band is narrow, its ends and their neighbours when it is wide
+    if (ranges[0][1] - ranges[0][0] + 1) * (ranges[1][1] - ranges[1][0] + 1) <= 200:
+        cand = [list(range(r[0], r[1] + 1)) for r in ranges]
+    else:
+        cand = [sorted({r[0], min(r[0] + 1, r[1]), max(r[1] - 1, r[0]), r[1]}) for r in ranges]
     errs = {}
-    for kc in range(ranges[0][0], ranges[0][1] + 1):
-        for ks in range(ranges[1][0], ranges[1][1] + 1):
-            want = np.asarray(fn(fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c), alpha, keep=(kc, ks))).reshape(nc, c)
-            errs[(kc, ks)] = rel_err(got, want)
-    print('near cut-off: C=%d scale 1e%.1f kept-count candidates %s -> best rel %.2e' % (c, log_scale, ranges, min(errs.values())))
-    assert min(errs.values()) < 1e-3, (c, nc, ns, alpha, mode, log_scale, errs)
+    for kc in cand[0]:
+        for ks in cand[1]:
+            errs[(kc, ks)] = rel_err(got, np.asarray(fn(*shaped, alpha, keep=(kc, ks))).reshape(nc, c))
+    # A WIDE band is a whole cluster of rounding-noise eigenvalues sitting on the cut-off (N < C pixels at a feature
+    # scale whose noise is ~1e-5 or above): every noise direction the reference happens to keep is amplified by up to
+    # (1e-5)^-1/2 = 316, and its own output is then rounding noise at the 1e-3..1e-2 level -- measured here as the
+    # distance between the oracle in float32 (the reference's arithmetic) and in float64.  No implementation can match
+    # what the reference does not determine; the tolerance follows that measured indeterminacy.
+    o32 = np.asarray(fn(*shaped, alpha)).reshape(nc, c)
+    o64 = np.asarray(fn(np.float64(shaped[0]), np.float64(shaped[1]), alpha, **({'dtype': np.float64} if mode == 'tf' else {}))).reshape(nc, c)
+    own = rel_err(o32, o64)
+    tol = max(1e-3, 4 * own)
+    STATS['wct_indeterminate'] += own > 2.5e-4
+    print('near cut-off: C=%d N=%d/%d scale 1e%.1f kept-count band %s: best rel %.2e (reference fp32 vs fp64 on this input: %.2e)'
+          % (c, nc, ns, log_scale, ranges, min(errs.values()), own))
+    assert min(errs.values()) < tol, (c, nc, ns, alpha, mode, log_scale, min(errs.values()), own)
 
 
 def test_wct_random_shapes_report():
     """Runs after the sweep above: how many of its cases had an eigenvalue inside the noise band of the cut-off
     (those were checked against the band of legitimate outcomes instead of being skipped)."""
-    print('WCT sweep: %(wct_cases)d cases, %(wct_near_cutoff)d with an eigenvalue within fp32 noise of the 1e-5 cut-off' % STATS)
+    print('WCT sweep: %(wct_cases)d cases, %(wct_near_cutoff)d with an eigenvalue within fp32 noise of the 1e-5 cut-off, '
+          '%(wct_indeterminate)d of those with a reference output that is itself rounding noise above 2.5e-4' % STATS)
     assert STATS['wct_cases'] >= 30
 
 

@@ -191,7 +191,7 @@ def test_every_conv_layer_at_full_size_teacher_forced(ctx, weights):
     h16 = lambda a: np.asarray(a, np.float16).astype(np.float32)    # noqa: E731
     img = np.float32(synthetic_image(7, 512, 512) / 255.)
     enc = weights['encoder']
-    x = oracle.conv1x1(img, *enc['preprocess'])
+    x = oracle.net_oracle.conv1x1(img, *enc['preprocess'])
     worst = 0.0
     for layer in ENCODER_LAYERS:
         if layer[0] == 'P':
