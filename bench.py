@@ -8,9 +8,14 @@ rank stylizes its own shard of independent pairs (no data-path collective) and, 
 the finished uint8 frames are gathered to rank 0 over RCCL at the end of every step.
 
 Prints ONE JSON line on rank 0 (see the driver contract): metric/value = whole-job stylized
-frames/sec, plus `roofline` for the dominant kernel class (conv3x3 on fp16 MFMA; achieved
-TFLOP/s from HIP events around every launch of that class on the library's stream) and
-`cpu_baseline` (the NumPy oracle of the same path timed on this host's cores, rank 0, N=1).
+frames/sec (device-resident batch throughput), plus `roofline` for the dominant kernel class
+(conv3x3 on fp16 MFMA; achieved TFLOP/s from HIP events around every launch of that class on the
+library's stream), `eigensolver` (the second-largest class), `latency_fps` (batch 1, host uint8
+in -> host uint8 out: SURVEY 8d asks for both figures) and `cpu_baseline` (BASELINE.md section 3:
+NumPy transform + torch-CPU conv stand-in on this host's cores, rank 0, N=1).
+
+Scaling modes: weak (default; --batch pairs per GPU per step) and strong (--global-batch G pairs
+per step in total: BASELINE configs[3] is --global-batch 64 on 8 GPUs = 8 pairs per GPU).
 """
 import argparse
 import json
@@ -59,27 +64,59 @@ def conv_flops_per_frame(size):
 
 
 def pmc_traffic(batch, size):
-    """HBM bytes per conv3x3 launch from the committed rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in
-    separate runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read
-    from inside this process, so the figure is the profile of this exact workload; null otherwise."""
-    path = os.path.join(ROOT, 'profiles', 'r01_final_pmc_conv3x3.json')
-    if batch != PMC_BATCH or size != 512 or not os.path.exists(path):
-        return None
-    return json.load(open(path))['hbm_bytes_per_launch_corrected']
+    """HBM bytes per conv3x3 launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
+    runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read from inside this
+    process, so the figure is the profile of this exact workload, not a measurement of this run; null otherwise."""
+    for tag in ('r02_final', 'r01_final'):
+        path = os.path.join(ROOT, 'profiles', '%s_pmc_conv3x3.json' % tag)
+        if batch == PMC_BATCH and size == 512 and os.path.exists(path):
+            return json.load(open(path))['hbm_bytes_per_launch_corrected'], 'profiles/%s_pmc_hbm.csv' % tag
+    return None, None
 
 
-def cpu_baseline(size, weights):
-    """The CPU oracle (NumPy restatement of the reference path, OpenBLAS threads) timed on a
-    bounded sample: ONE frame of the same workload."""
-    import oracle
+def cpu_baseline(size, weights, alpha):
+    """the reference's path on this host's cores -- its transform in NumPy (oracle.wct_tf, the
+    restatement pinned to the reference's own wct_np outputs at these sizes) around a torch-CPU STAND-IN for the
+    CPU-TensorFlow conv stack (oracle/torch_path.py: reflect pad + conv2d + max_pool2d(ceil) + nearest upsample, same
+    weights, same frames).  One warm-up frame, then the median of 5 frames.  A reported baseline, not the target."""
+    import torch
+    from oracle.torch_path import TorchPath
     from wct_tf_amd.weights import synthetic_image
+    path = TorchPath(weights)
     c = synthetic_image(1000, size, size)
     s = synthetic_image(2000, size, size)
-    t0 = time.time()
-    oracle.stylize(c, s, weights, LEVELS, alpha=0.8, wct_mode='tf')
-    dt = time.time() - t0
-    return {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': '1 frame %dx%d, 5-level, alpha 0.8, NumPy oracle (im2col+OpenBLAS convs, LAPACK SVD), %.1f s' % (size, size, dt)}
+    path.stylize(c, s, LEVELS, alpha, 'tf')
+    times = []
+    for _ in range(5):
+        t0 = time.time()
+        path.stylize(c, s, LEVELS, alpha, 'tf')
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    try:
+        from threadpoolctl import threadpool_info
+        blas = max([p.get('num_threads', 0) for p in threadpool_info() if p.get('user_api') == 'blas'] or [0])
+    except Exception:
+        blas = 0
+    return {'value': 1.0 / med, 'unit': 'frames/s', 'cores': max(torch.get_num_threads(), blas), 'kind': 'port',
+            'host_cores': os.cpu_count(), 'torch_threads': torch.get_num_threads(), 'blas_threads': blas,
+            'sample': '1 warm-up + median of 5 frames %dx%d, 5-level, alpha %.1f: NumPy transform (restatement of the reference\'s '
+                      'wct_tf/wct_np, LAPACK SVD) + torch-CPU stand-in for the CPU-TF conv stack; %.2f s per frame '
+                      '(min %.2f, max %.2f)' % (size, size, alpha, med, min(times), max(times))}
+
+
+def latency_leg(ctx, size, alpha, n=20):
+    """SURVEY 8d latency mode: ONE predict() -- host uint8 content + style in, host uint8 frame out (wct_stylize,
+    PCIe transfers included), batch 1, style recomputed."""
+    from wct_tf_amd.weights import synthetic_image
+    c, s = synthetic_image(1000, size, size), synthetic_image(2000, size, size)
+    for _ in range(3):
+        ctx.stylize(c, s, LEVELS, alpha=alpha)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        ctx.stylize(c, s, LEVELS, alpha=alpha)
+    dt = (time.perf_counter() - t0) / n
+    return {'latency_fps': 1.0 / dt, 'latency_ms': 1e3 * dt,
+            'latency_note': 'batch 1, wct_stylize: host uint8 in -> host uint8 out, mean of %d calls' % n}
 
 
 def main():
@@ -87,13 +124,17 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=32, help='independent content/style pairs per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='weak scaling (default): independent content/style pairs per GPU per step')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling: this many pairs per step IN TOTAL, sharded over the GPUs (BASELINE configs[3]: 64 over '
+                         '8 GPUs = 8 per GPU); 0 = weak scaling with --batch pairs per GPU')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--alpha', type=float, default=0.8)
     ap.add_argument('--shared-style', action='store_true',
                     help='NOT the headline metric: every pair of a step uses ONE style image (fixed-style video, '
                          'WCT_FLAG_STYLE_SHARED): the style side runs once per step instead of once per frame')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 host-in/host-out latency leg')
     ap.add_argument('--no-prof', action='store_true', help='no per-class HIP-event timing inside the timed region')
     args = ap.parse_args()
 
@@ -124,30 +165,60 @@ def main():
     ctx = Context(local_rank)
     ctx.set_weights(weights)
 
-    B, S = args.batch, args.size
-    total_pairs = B * world
+    S = args.size
+    strong = args.global_batch > 0
+    total_pairs = args.global_batch if strong else args.batch * world
     lo, hi = shard_range(total_pairs, world, rank)                         # contiguous shard of the global batch
-    content = np.stack([synthetic_image(1000 + i, S, S) for i in range(lo, hi)])
-    style = np.stack([synthetic_image(2000 + i, S, S) for i in range(lo, hi)])
+    n_local = hi - lo
+    content = np.stack([synthetic_image(1000 + i, S, S) for i in range(lo, hi)]) if n_local else np.zeros((0, S, S, 3), np.uint8)
+    style = np.stack([synthetic_image(2000 + i, S, S) for i in range(lo, hi)]) if n_local else np.zeros((0, S, S, 3), np.uint8)
     if args.shared_style:
-        style = style[0]
+        style = style[:1]
     dev = torch.device('cuda', local_rank)
     d_content = torch.from_numpy(content).to(dev)                          # inputs resident in HBM
     d_style = torch.from_numpy(style).to(dev)
-    d_out = torch.empty_like(d_content)
+    # two output buffers: the gather of step k reads one while step k+1 writes the other
+    d_out = [torch.empty_like(d_content), torch.empty_like(d_content)]
     torch.cuda.synchronize()
 
     import ctypes as C
+    LIB_MAX = 32                                                            # pairs per library call
+    chunks = [(a, min(n_local, a + LIB_MAX)) for a in range(0, n_local, LIB_MAX)]
+    frame_bytes = S * S * 3
+
+    def compute(out):
+        for a, b in chunks:
+            sp = d_style.data_ptr() if args.shared_style else d_style.data_ptr() + a * frame_bytes
+            ctx.stylize_batch_dev(C.c_void_p(d_content.data_ptr() + a * frame_bytes), S, S, C.c_void_p(sp), S, S, b - a, LEVELS,
+                                  args.alpha, C.c_void_p(out.data_ptr() + a * frame_bytes), shared_style=args.shared_style)
+
+    # WCT_BENCH_FORCE_OVERLAP=1: run the event protocol of the overlapped gather on a single rank too (tests)
+    overlap = (world > 1 and backend == 'nccl') or bool(os.environ.get('WCT_BENCH_FORCE_OVERLAP'))
+    if overlap:
+        # the library's stream as a torch stream: events order the RCCL gather behind the frames and the next write of
+        # a buffer behind the gather that still reads it -- no host synchronisation between the steps
+        lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+        comm = torch.cuda.Stream(dev)
+        done_compute = [torch.cuda.Event(), torch.cuda.Event()]
+        done_gather = [torch.cuda.Event(), torch.cuda.Event()]
+    state = {'k': 0, 'frames': None}
 
     def step():
-        ctx.stylize_batch_dev(C.c_void_p(d_content.data_ptr()), S, S, C.c_void_p(d_style.data_ptr()), S, S,
-                              B, LEVELS, args.alpha, C.c_void_p(d_out.data_ptr()), shared_style=args.shared_style)
-        if world > 1:
-            ctx.sync()                                                     # library stream -> torch stream hand-off
-            frames = gather_frames(d_out if backend == 'nccl' else d_out.cpu(), world, rank)
-            torch.cuda.synchronize()                                       # RCCL must be done with d_out before the
-            return frames                                                  # next step overwrites it on the library stream
-        return None
+        k = state['k'] & 1
+        state['k'] += 1
+        if not overlap:
+            compute(d_out[k])
+            if world > 1:                                                  # dry run: stage through the host (gloo)
+                ctx.sync()
+                state['frames'] = gather_frames(d_out[k].cpu(), world, rank, n_items=total_pairs)
+            return
+        lib_stream.wait_event(done_gather[k])                              # buffer k was last read by the gather two steps ago
+        compute(d_out[k])
+        done_compute[k].record(lib_stream)
+        comm.wait_event(done_compute[k])
+        with torch.cuda.stream(comm):                                      # overlaps the next step's kernels
+            state['frames'] = gather_frames(d_out[k], world, rank, n_items=total_pairs)
+            done_gather[k].record(comm)
 
     def barrier():
         ctx.sync()
@@ -171,41 +242,58 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if rank == 0:
+            assert state['frames'] is not None and state['frames'].shape[0] == total_pairs
 
     prof = None if args.no_prof else ctx.prof_read()
     if rank == 0:
         frames = total_pairs * args.steps
         fps = frames / dt
+        per_gpu = '%d' % (total_pairs // world) if total_pairs % world == 0 else '%d-%d' % (total_pairs // world, total_pairs // world + 1)
         line = {
             'metric': 'stylized frames/sec @512x512, 5-level relu5->1 pipeline, alpha=0.8',
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': 'configs[2]: full 5-level relu5_1->relu1_1, %dx%d content+style, alpha %.1f, '
                                    'wct_tf semantics, %s' % (S, S, args.alpha, 'ONE style per step (fixed-style video mode, not the headline '
                                    'metric)' if args.shared_style else 'style features recomputed per frame'),
-                       'pairs_per_gpu_per_step': B, 'global_batch': total_pairs,
-                       'parallelism': 'pairs sharded over %d GPU(s), RCCL gather of uint8 frames' % world,
+                       'pairs_per_gpu_per_step': n_local if world == 1 else per_gpu, 'global_batch': total_pairs,
+                       'parallelism': ('strong scaling: %d pairs per step sharded over %d GPU(s) (%s per GPU; BASELINE configs[3] is 64 over 8)'
+                                       if strong else 'weak scaling: %d pairs per step = %d GPU(s) x %s') % (total_pairs, world, per_gpu)
+                                      + ', no data-path collective, one RCCL gather of the uint8 frames per step overlapped with the next step',
                        'weights': 'synthetic He-normal seed 42 (no pre-trained weights offline)'},
         }
         if prof is not None:
             conv = prof['conv3x3']
             ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
+            traffic, traffic_src = pmc_traffic(n_local, S)
             line['roofline'] = {
                 'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / MFMA_F16_DENSE_PEAK_TFLOPS, 'traffic': pmc_traffic(B, S),
-                'traffic_unit': 'HBM bytes per launch (rocprofv3 PMC, profiles/r01_final_pmc_hbm.csv)',
+                'frac': ach / MFMA_F16_DENSE_PEAK_TFLOPS, 'traffic': traffic,
+                'traffic_unit': 'HBM bytes per launch; NOT measured in this run: the committed rocprofv3 PMC passes of this '
+                                'workload (%s)' % traffic_src if traffic else 'no committed PMC pass for this batch/size',
                 'algorithmic_bytes_per_launch': conv['bytes'] / max(1, conv['launches']),
-                'kernel': 'conv3x3_mfma_kernel (all launches of the class)',
+                'kernel': 'conv3x3_mfma_kernel (all launches of the class: the largest time class of the step)',
                 'launches': conv['launches'], 'avg_launch_ms': conv['ms'] / max(1, conv['launches']),
                 'algorithmic_flops_per_frame': conv_flops_per_frame(S),
                 'algorithmic_gbytes_per_s': conv['bytes'] / (conv['ms'] * 1e-3) / 1e9 if conv['ms'] > 0 else 0.0,
             }
+            step_ms = 1e3 * dt / args.steps
+            jac = prof['jacobi']
+            line['eigensolver'] = {
+                'ms_per_step': jac['ms'] / args.steps, 'share_of_step': jac['ms'] / args.steps / step_ms,
+                'matrices_per_step': 2 * 5 * n_local, 'bound': 'latency of the serial rotation sets + fp32-MFMA tile updates',
+                'note': 'batched two-sided block Jacobi on the %d-level covariances (C = 512, 512, 256, 128, 64; content and style); '
+                        'second-largest time class' % len(LEVELS)}
             line['breakdown_ms_per_step'] = {k: v['ms'] / args.steps for k, v in prof.items()}
+        if world == 1 and not args.no_latency and not args.shared_style:
+            line.update(latency_leg(ctx, S, args.alpha))
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(S, weights)
+            line['cpu_baseline'] = cpu_baseline(S, weights, args.alpha)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 

@@ -59,6 +59,10 @@ const char* wct_last_error(void);
 int  wct_sync(wct_ctx* ctx);                       /* block until the ctx stream is idle; WCT_STATUS_NOCONV if an
                                                        eigensolve of the work just completed failed (see above) */
 int  wct_device_count(int* n);
+/* The ctx's HIP stream (a hipStream_t), so that a caller can order its own device work -- e.g. the RCCL gather of the
+ * finished frames, multi-GPU runs -- behind wct_stylize_batch_dev without a host sync (record an event on it, wait for
+ * the event on the other stream).  The reference has no counterpart: its session is blocking (wct.py:97-104). */
+int  wct_get_stream(wct_ctx* ctx, void** stream_out);
 
 /* ---- weights: replace vgg_from_t7 (vgg_normalised.py:10-55) and the per-decoder
  * Saver.restore (wct.py:46-58).  The library copies, folds the 1x1 'preprocess'

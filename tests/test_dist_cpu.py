@@ -33,7 +33,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_items, q):
+def _worker(rank, world, port, n_items, q, static):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -41,7 +41,7 @@ def _worker(rank, world, port, n_items, q):
     # "stylized frames" of this shard: frame i is filled with value i
     frames = torch.stack([torch.full((4, 6, 3), i, dtype=torch.uint8) for i in range(lo, hi)]) \
         if hi > lo else torch.zeros((0, 4, 6, 3), dtype=torch.uint8)
-    out = gather_frames(frames, world, rank)
+    out = gather_frames(frames, world, rank, n_items=n_items if static else None)
     if rank == 0:
         q.put(out.numpy())
     else:
@@ -50,12 +50,14 @@ def _worker(rank, world, port, n_items, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_items', [8, 5])
-def test_gather_frames_world2_gloo(n_items):
+@pytest.mark.parametrize('n_items,static', [(8, True), (5, True), (5, False)])
+def test_gather_frames_world2_gloo(n_items, static):
+    """static: the sizes follow from the shard map (one gather, nothing else: what bench.py and the CLI use);
+    not static: sizes exchanged first."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q, static)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)

@@ -412,6 +412,51 @@ def test_pipeline_reports_failed_eigensolves_at_sync(ctx, weights):
     assert np.array_equal(ctx.stylize(c, s, targets, alpha=0.8), good)
 
 
+def test_stream_handle_orders_foreign_work(ctx, weights):
+    """wct_get_stream: a caller's own stream can be ordered behind wct_stylize_batch_dev with events alone (what the
+    multi-GPU bench does with the RCCL gather) -- no host sync between the library's kernels and the foreign copy."""
+    import ctypes as C
+    import torch
+    targets = ['relu3_1', 'relu1_1']
+    B = 4
+    cs = np.stack([synthetic_image(1100 + i, 96, 96) for i in range(B)])
+    ss = np.stack([synthetic_image(2100 + i, 96, 96) for i in range(B)])
+    dev = torch.device('cuda', 0)
+    dc, ds = torch.from_numpy(cs).to(dev), torch.from_numpy(ss).to(dev)
+    out = torch.zeros_like(dc)
+    torch.cuda.synchronize()
+    lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+    side = torch.cuda.Stream(dev)
+    ev = torch.cuda.Event()
+    ctx.stylize_batch_dev(C.c_void_p(dc.data_ptr()), 96, 96, C.c_void_p(ds.data_ptr()), 96, 96, B, targets, 0.8, C.c_void_p(out.data_ptr()))
+    ev.record(lib_stream)
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        copy = out.clone()
+    side.synchronize()
+    ctx.sync()
+    for i in range(B):
+        assert np.array_equal(copy[i].cpu().numpy(), ctx.stylize(cs[i], ss[i], targets, alpha=0.8)), i
+
+
+def test_bench_cli_small(tmp_path):
+    """bench.py end to end on a small configuration: the JSON contract (metric, value, roofline, eigensolver, latency),
+    the strong-scaling mode, and the event protocol of the overlapped gather (forced on the single rank)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WCT_BENCH_FORCE_OVERLAP='1')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--size', '64', '--global-batch', '6', '--steps', '2',
+                          '--warmup', '1', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['scaling'] == 'strong' and line['config']['global_batch'] == 6 and line['n_gpus'] == 1
+    assert line['value'] > 0 and line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1
+    assert line['eigensolver']['ms_per_step'] > 0 and line['latency_fps'] > 0
+    assert abs(sum(line['breakdown_ms_per_step'].values()) - line['ms_per_step']) < 0.5 * line['ms_per_step']
+
+
 def test_swap5_pipeline(ctx, weights):
     """--swap5: style-swap at relu5_1 (priority over adain), WCT below.  The fused call must equal the
     GPU ops chained by hand; the relu5_1 op is checked against the oracle on the oracle's features."""

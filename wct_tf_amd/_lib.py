@@ -25,6 +25,7 @@ SIGNATURES = [
     ('wct_last_error', C.c_char_p, []),
     ('wct_sync', C.c_int, [_P]),
     ('wct_device_count', C.c_int, [_I]),
+    ('wct_get_stream', C.c_int, [_P, _PP]),
     ('wct_set_encoder', C.c_int, [_P, _F, _F, C.POINTER(_F), C.POINTER(_F), C.c_int]),
     ('wct_set_decoder', C.c_int, [_P, C.c_int, C.POINTER(_F), C.POINTER(_F), C.c_int]),
     ('wct_transform', C.c_int, [_P, _F, C.c_int, _F, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _F, _I]),

@@ -49,6 +49,12 @@ class Context(object):
     def sync(self):
         check(self.lib.wct_sync(self.h))
 
+    def stream_handle(self):
+        """The context's hipStream_t as an integer (torch.cuda.ExternalStream(handle) wraps it)."""
+        p = C.c_void_p()
+        check(self.lib.wct_get_stream(self.h, C.byref(p)))
+        return p.value or 0
+
     # ---- weights ---------------------------------------------------------
     def set_encoder(self, enc):
         pre_w, pre_b = enc['preprocess']

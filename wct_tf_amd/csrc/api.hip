@@ -221,6 +221,12 @@ extern "C" int wct_sync(wct_ctx* c) {
   return eig_status(c);
 }
 
+extern "C" int wct_get_stream(wct_ctx* c, void** stream_out) {
+  ARG_CHECK(c && stream_out);
+  *stream_out = (void*)c->stream;
+  return WCT_OK;
+}
+
 extern "C" int wct_dev_alloc(wct_ctx* c, size_t bytes, void** out) {
   ARG_CHECK(c && out && bytes > 0);
   HIP_TRY(hipSetDevice(c->device));

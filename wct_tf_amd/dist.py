@@ -19,16 +19,26 @@ def shard_range(n_items, world_size, rank):
     return lo, hi
 
 
-def gather_frames(local_frames, world_size, rank, dst=0):
+def gather_frames(local_frames, world_size, rank, dst=0, n_items=None):
     """Gather every rank's [b, H, W, 3] uint8 frames on `dst`; returns the [sum b, H, W, 3]
     tensor there (rank order == global pair order of shard_range) and None elsewhere.
-    Equal shard sizes use one dist.gather; ragged shards pad to the largest."""
+
+    The shard map is static, so every rank knows every shard size: with `n_items` (the global
+    number of pairs) given, the exchange is ONE dist.gather and nothing else -- no size
+    exchange, no host synchronisation.  Ragged shards pad to the largest.  Without `n_items`
+    the sizes are exchanged first (an all_gather and a host read-back: only for callers whose
+    shards do not come from shard_range)."""
     if world_size == 1:
         return local_frames
-    b = torch.tensor([local_frames.shape[0]], dtype=torch.int64, device=local_frames.device)
-    sizes = [torch.zeros_like(b) for _ in range(world_size)]
-    dist.all_gather(sizes, b)
-    sizes = [int(s.item()) for s in sizes]
+    if n_items is not None:
+        sizes = [shard_range(n_items, world_size, r)[1] - shard_range(n_items, world_size, r)[0] for r in range(world_size)]
+        if sizes[rank] != local_frames.shape[0]:
+            raise ValueError('rank %d holds %d frames, its shard of %d items has %d' % (rank, local_frames.shape[0], n_items, sizes[rank]))
+    else:
+        b = torch.tensor([local_frames.shape[0]], dtype=torch.int64, device=local_frames.device)
+        got = [torch.zeros_like(b) for _ in range(world_size)]
+        dist.all_gather(got, b)
+        sizes = [int(s.item()) for s in got]
     bmax = max(sizes)
     send = local_frames
     if send.shape[0] != bmax:
@@ -38,6 +48,8 @@ def gather_frames(local_frames, world_size, rank, dst=0):
     if rank == dst:
         parts = [torch.empty_like(send) for _ in range(world_size)]
         dist.gather(send, gather_list=parts, dst=dst)
+        if all(n == bmax for n in sizes):
+            return torch.cat(parts, 0)
         return torch.cat([p[:n] for p, n in zip(parts, sizes)], 0)
     dist.gather(send, gather_list=None, dst=dst)
     return None
