@@ -61,8 +61,15 @@ def test_model_descriptor_mirrors_reference_attributes():
         assert hasattr(m, attr)
     assert m.deepest_target == 'relu3_1' and len(m.encoder_decoders) == 2
     assert m.encoder_decoders[1].content_input == 'clip(relu3_1.decoded)'
-    with pytest.raises(NotImplementedError):
-        WCTModel(mode='train')
+    assert m.encoder_decoders[0].train_op is None and m.encoder_decoders[0].total_loss is None      # model.py:206-208
+    t = WCTModel(mode='train', relu_targets=['relu2_1'], batch_size=4, feature_weight=2.0, learning_rate=1e-3, lr_decay=0.1)
+    ed = t.encoder_decoders[0]
+    assert ed.train_op['call'] == 'wct_train_step' and ed.train_op['level'] == 2
+    assert ed.total_loss is not None and ed.decoded_encoded is not None and t.feature_weight == 2.0
+    with pytest.raises(RuntimeError):
+        m.train_step(None, None, 0)
+    with pytest.raises(ValueError):
+        WCTModel(mode='predict')
 
 
 def test_weights_roundtrip(tmp_path):

@@ -58,6 +58,50 @@ def test_bundle_round_trip(tmp_path, block_size, shards):
     assert len(tf_ckpt.decoder_weights_from_checkpoint(os.path.join(d, 'model.ckpt-15000'), 'relu1_1')) == 2
 
 
+def test_twin_decoder_variable_sets(tmp_path):
+    """ADVICE r1: the reference builds every decoder twice (the Conv2D of Conv2DReflect lives in a Lambda, ops.py:17-19;
+    build_decoder instantiates it and decoder_model(...) at model.py:171 instantiates it again), so a real checkpoint
+    can hold the trained set under .../decoder_model_<relu>/... AND an untrained twin under .../decoder_<relu>/<relu>_N/.
+    Both match wct.py:48-49's selection.  The trained set (it owns Adam slots / sits in the decoder_model scope) must
+    win whatever the name order; twins that cannot be told apart are an error, not a silent pick."""
+    rng = np.random.default_rng(5)
+    relu = 'relu2_1'
+    t, want = decoder_variables(relu, rng)                       # trained set, with Adam slots
+    twin_scope = 'encoder_decoder_{r}/decoder_{r}/'.format(r=relu)
+    count = 0
+    for kind, cin, cout, _ in decoder_plan(relu):
+        if kind == 'U':
+            count += 1
+            continue
+        base = twin_scope + '%s_%d/' % (relu, count)
+        t[base + 'kernel'] = rng.standard_normal((3, 3, cin, cout)).astype(np.float32)      # untrained: no slots
+        t[base + 'bias'] = np.zeros(cout, np.float32)
+        count += 1
+    d = str(tmp_path / 'a')
+    os.makedirs(d)
+    write_bundle(os.path.join(d, 'model.ckpt-9'), t, block_size=256)
+    write_checkpoint_state(d, 'model.ckpt-9')
+    got = tf_ckpt.decoder_weights_from_checkpoint(d, relu)
+    for (w, b), (w0, b0) in zip(got, want):
+        assert np.array_equal(w, w0) and np.array_equal(b, b0)
+    # without optimiser slots the decoder_model_<relu> scope still identifies the set decoder_model(...) uses
+    t2 = {k: v for k, v in t.items() if '/Adam' not in k}
+    d2 = str(tmp_path / 'b')
+    os.makedirs(d2)
+    write_bundle(os.path.join(d2, 'model.ckpt-9'), t2, block_size=256)
+    write_checkpoint_state(d2, 'model.ckpt-9')
+    got = tf_ckpt.decoder_weights_from_checkpoint(d2, relu)
+    assert all(np.array_equal(w, w0) for (w, _), (w0, _) in zip(got, want))
+    # two indistinguishable sets: refuse
+    t3 = {k.replace('decoder_model_' + relu, 'other_scope'): v for k, v in t2.items()}
+    d3 = str(tmp_path / 'c')
+    os.makedirs(d3)
+    write_bundle(os.path.join(d3, 'model.ckpt-9'), t3, block_size=256)
+    write_checkpoint_state(d3, 'model.ckpt-9')
+    with pytest.raises(tf_ckpt.CheckpointError, match='stored 2 times'):
+        tf_ckpt.decoder_weights_from_checkpoint(d3, relu)
+
+
 def test_bundle_errors(tmp_path):
     rng = np.random.default_rng(2)
     t, _ = decoder_variables('relu1_1', rng, with_slots=False)

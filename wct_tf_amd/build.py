@@ -1,4 +1,5 @@
 """Build libwct_hip.so (gfx950) in-tree with hipcc.  `python -m wct_tf_amd.build`."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -9,13 +10,27 @@ LIB = os.path.join(HERE, 'libwct_hip.so')
 SOURCES = ['api.hip', 'conv.hip', 'wct.hip', 'coral.hip', 'train.hip']
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith('.o')]
+STAMP = LIB + '.src.sha256'
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result']
+
+
+def source_digest():
+    """sha256 over every source the library is built from (csrc/*.hip, *.h, the public header) and the flags."""
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
     deps.append(os.path.join(os.path.dirname(HERE), 'include', 'wct_hip.h'))
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, 'rb').read())
+    return h.hexdigest()
+
+
+def needs_build():
+    """The .so is current iff the digest stored beside it equals the digest of the sources as they are now
+    (modification times do not survive a snapshot to the GPU box; content does)."""
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return True
+    return open(STAMP).read().strip() != source_digest()
 
 
 def build(force=False, verbose=True):
@@ -25,8 +40,7 @@ def build(force=False, verbose=True):
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value', '-Wno-unused-result', '-c',
-               os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -35,6 +49,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, 'w') as f:
+        f.write(source_digest() + '\n')
     return LIB
 
 

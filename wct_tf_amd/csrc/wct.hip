@@ -1778,7 +1778,8 @@ __global__ __launch_bounds__(64) void row_argmax_kernel(const float* E, int* idx
     const int oi = __shfl_xor(bi, o, 64);
     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
   }
-  if (lane == 0) idx[m] = bi;
+  // a row of NaN / -inf correlations (non-finite features) leaves no winner: keep the gather in bounds
+  if (lane == 0) idx[m] = (bi >= 0 && bi < n) ? bi : 0;
 }
 
 // overlap-add of the winning patches divided by the coverage count (ops.py:255-276), as a gather

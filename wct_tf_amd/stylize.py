@@ -16,7 +16,7 @@ from .wct import WCT
 _FLAGS = [
     (('--checkpoints',), dict(nargs='+', default=None, help='one decoder checkpoint (directory or .npz) per relu target')),
     (('--relu-targets',), dict(nargs='+', required=True, help='relu layers to stylize at, in pipeline order')),
-    (('--vgg-path',), dict(default=None, help='encoder weights: vgg_normalised.t7 or .npz')),
+    (('--vgg-path',), dict(default='models/vgg_normalised.t7', help='encoder weights: vgg_normalised.t7 or .npz (stylize.py:19 default)')),
     (('--content-path',), dict(dest='content_path', help='content image, or a folder of them')),
     (('--style-path',), dict(dest='style_path', help='style image, or a folder of them')),
     (('--out-path',), dict(dest='out_path', help='folder the results are written to')),
@@ -92,7 +92,10 @@ def stylize_pair(model, content, style, args):
 
 
 def main(argv=None):
-    args = build_parser().parse_args(argv)
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    if args.synthetic_weights is None and not args.checkpoints:
+        parser.error('--checkpoints is required (stylize.py:17) unless --synthetic-weights SEED is given')
     t0 = time.time()
     weights = None
     if args.synthetic_weights is not None:

@@ -34,7 +34,7 @@ TMP_DIR = '_____fns_frames_%s/' % random.randint(0, 99999)
 _FLAGS = [
     (('--checkpoints',), dict(nargs='+', default=None, help='one decoder checkpoint (directory or .npz) per relu target')),
     (('--relu-targets',), dict(nargs='+', required=True, help='relu layers to stylize at, in pipeline order')),
-    (('--vgg-path',), dict(default=None, help='encoder weights: vgg_normalised.t7 or .npz')),
+    (('--vgg-path',), dict(default='models/vgg_normalised.t7', help='encoder weights: vgg_normalised.t7 or .npz (stylize.py:19 default)')),
     (('--in-path',), dict(required=True, help='a video file (needs ffmpeg on PATH) or a directory of frames')),
     (('--out-path',), dict(required=True, help='folder the results are written to')),
     (('--style-path',), dict(required=True, help='style image, or a folder of them (one output per style)')),
@@ -123,7 +123,10 @@ def stylize_frames(wct_model, frame_files, style_img, args):
 
 
 def main(argv=None):
-    args = build_parser().parse_args(argv)
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    if args.synthetic_weights is None and not args.checkpoints:
+        parser.error('--checkpoints is required (stylize.py:17) unless --synthetic-weights SEED is given')
     start = time.time()
     weights = None
     if args.synthetic_weights is not None:

@@ -297,15 +297,36 @@ def decoder_weights_from_checkpoint(checkpoint, relu_target, verify_crc=False):
     b = Bundle(prefix)
     tag = 'decoder_' + relu_target
     layer_re = re.compile(r'(?:^|/)%s_(\d+)(?:/|$)' % re.escape(relu_target))
-    layers = {}
-    for name in b.names():
+    names = b.names()
+    slotted = {_SLOT.sub('', n) for n in names if _SLOT.search(n)}       # variables the optimiser holds moments for
+    cands = {}
+    for name in names:
         if tag not in name or _SLOT.search(name):
             continue
         leaf = name.rsplit('/', 1)[-1]
         m = layer_re.search(name)
         if leaf not in ('kernel', 'bias') or not m:
             continue
-        layers.setdefault(int(m.group(1)), {})[leaf] = name
+        cands.setdefault((int(m.group(1)), leaf), []).append(name)
+    # The reference instantiates each decoder TWICE: Conv2DReflect builds its Conv2D inside a Lambda (ops.py:17-19), once
+    # when build_decoder assembles the Keras model and once more when decoder_model(...) is applied (model.py:171), so a
+    # real checkpoint can hold a trained set under .../decoder_model_<relu>/... and an untrained twin beside it.  Both
+    # match the selection of wct.py:48-49.  Prefer the set the optimiser trained (it owns Adam slots), then the one
+    # under the decoder_model_<relu> scope; anything still ambiguous is an error, never a silent pick.
+    layers = {}
+    model_scope = 'decoder_model_' + relu_target + '/'
+    for (idx, leaf), group in cands.items():
+        pick = group
+        if len(pick) > 1:
+            trained = [n for n in pick if n in slotted]
+            pick = trained or pick
+        if len(pick) > 1:
+            scoped = [n for n in pick if model_scope in n]
+            pick = scoped or pick
+        if len(pick) > 1:
+            raise CheckpointError('%s_%d/%s is stored %d times and nothing tells the trained copy apart: %s'
+                                  % (relu_target, idx, leaf, len(pick), ', '.join(sorted(pick))))
+        layers.setdefault(idx, {})[leaf] = pick[0]
     if not layers:
         raise Exception('No variables containing {} in checkpoint {}'.format(tag, prefix))
     out = []

@@ -16,6 +16,19 @@ Differences from the reference, forced by the environment: no TensorFlow, so no 
 Checkpoints are `decoder_<relu>.npz` files in --checkpoint (the layout `WCT(checkpoints=[dir])` reads back) plus a
 `train_state.json` with the step counter; `--max-to-keep` numbered snapshots are rotated like the Saver does.
 `--synthetic-weights SEED` / `--synthetic-data N` stand in for the absent VGG file / image folder.
+
+Optimiser state: a checkpoint holds the decoder weights and the global step, NOT Adam's moments (tf.train.Saver also
+stores the Adam slots).  After a restore -- at start-up or after a failed step -- the moments restart at zero, and so
+does the step count of Adam's bias correction (`opt_step` below): with a large global step and zero moments the
+correction would be ~1 and the first updates ~3x too large.  The learning-rate decay keeps following the global step.
+A fresh decoder starts from seeded He-normal filters with zero-mean kernels and a 0.5 bias on the output conv
+(`weights.synthetic_weights(0)`), not from Keras' glorot_uniform / zero bias: there is no Keras here to reproduce
+its random stream, and the start only matters for the first few hundred steps.
+
+Data-parallel failures: a rank-local exception inside the local phase of a step (gradients of the rank's own batch)
+is agreed on by ALL ranks (MIN all-reduce of an ok flag) before any of them acts, so every rank reloads the same
+checkpoint together and the collectives stay paired; a failure inside the collective phase (all-reduce, apply)
+cannot be recovered rank-locally and aborts the job.
 """
 from __future__ import division, print_function
 
@@ -209,23 +222,50 @@ def train(argv=None):
             grad[0] = torch.as_tensor(_DevArray(ptr, count), device='cuda:%d' % args.device)     # a view, no copy
     bind_grad()
 
+    class StepFailed(Exception):
+        """a step every rank agreed to abandon (recoverable: reload the latest checkpoint everywhere)"""
+
+    def agree(ok, err):
+        """data parallel: True only if EVERY rank's local phase succeeded; all ranks raise together otherwise"""
+        if dist is None:
+            if not ok:
+                raise StepFailed(str(err))
+            return
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                            device='cuda:%d' % args.device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            raise StepFailed(str(err) if err is not None else 'another rank failed this step')
+
     def one_step(x, step, lr):
-        """single GPU: one fused call; data parallel: gradients, one all-reduce (average), the same Adam everywhere"""
-        if dist is None or lr == 0.0:
-            res = ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
-                                 pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+        """single GPU: one fused call; data parallel: gradients, one all-reduce (average), the same Adam everywhere.
+        `step` is the optimiser's own step count (Adam bias correction), see the module docstring."""
+        if dist is None:
+            try:
+                res = ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
+                                     pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+            except Exception as e:                  # noqa: BLE001
+                raise StepFailed(str(e))
         else:
-            res = ctx.train_step(relu, x, step=step, learning_rate=0.0, feature_weight=args.feature_weight,
-                                 pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
-            if dist.get_backend() == 'nccl':
+            res, err = None, None
+            try:                                    # local phase: may fail on one rank only
+                res = ctx.train_step(relu, x, step=step, learning_rate=0.0, feature_weight=args.feature_weight,
+                                     pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+            except Exception as e:                  # noqa: BLE001
+                err = e
+            agree(err is None, err)
+            if lr == 0.0:
+                pass                                # evaluation only (validation batch): no update
+            elif dist.get_backend() == 'nccl':
                 dist.all_reduce(grad[0], op=dist.ReduceOp.SUM)
                 grad[0].div_(world)
             else:                                   # host-staged dry run
                 host = grad[0].cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
                 grad[0].copy_(host / world)
-            torch.cuda.synchronize()
-            ctx.train_apply(relu, step, lr)
+            if lr != 0.0:
+                torch.cuda.synchronize()
+                ctx.train_apply(relu, step, lr)     # collective phase: an exception here ends the job (not caught below)
         if dist is not None:
             t = torch.tensor([res['feature_loss'], res['pixel_loss'], res['tv_loss'], res['total_loss']], dtype=torch.float64,
                              device='cuda:%d' % args.device if dist.get_backend() == 'nccl' else 'cpu')
@@ -235,29 +275,33 @@ def train(argv=None):
         return res
 
     step = step0
+    opt_step = 0                                    # steps since Adam's moments were last zero (see the module docstring)
     results = None
     for iteration in range(args.max_iter):
         start = time.time()
         x = train_q.get()
         lr = torch_decay(args.learning_rate, step, args.lr_decay)
         step += 1
+        opt_step += 1
         try:
-            results = one_step(x, step, lr)
-            if not np.isfinite(results['total_loss']):
-                raise FloatingPointError('non-finite loss at step %d' % step)
-        except Exception as e:                     # noqa: BLE001  train.py:168-174: reload the latest checkpoint and go on
+            results = one_step(x, opt_step, lr)
+            if not np.isfinite(results['total_loss']):     # the loss is averaged over ranks: every rank sees the same value
+                raise StepFailed('non-finite loss at step %d' % step)
+        except StepFailed as e:                    # train.py:168-174: reload the latest checkpoint and go on -- all ranks together
             print(e)
             print('Exception encountered, re-loading latest checkpoint')
             restored, step_saved = load_latest(args.checkpoint, relu)
             if restored is None:
                 raise
-            ctx.set_decoder(relu, restored)        # fresh optimiser state, as a restored graph would have saved ones
+            ctx.set_decoder(relu, restored)        # zero moments: the bias correction restarts with them
             bind_grad()                            # the gradient buffer was re-created with the decoder
-            step = step_saved
+            step, opt_step = step_saved, 0
+            if dist is not None:
+                dist.barrier()
             continue
         rec = dict(results, step=step, lr=lr, time=time.time() - start)
         if iteration % args.summary_iter == 0:          # a validation batch, evaluated without an update
-            val = one_step(val_q.get(), step, 0.0)
+            val = one_step(val_q.get(), max(opt_step, 1), 0.0)
             rec['val_total_loss'] = val['total_loss']
         if rank == 0:
             log.write(json.dumps(rec) + '\n')
