@@ -1129,10 +1129,15 @@ static JacobiHost* jacobi_host() {
   return &h;
 }
 
-// the pivot-wave cross sweep (jacobi_cross_sets_pw) is the default; WCT_JACOBI_PW=0 selects the round-1 kernel
-static bool jacobi_use_pw() {
+// cross-step kernel: 1 = pivot wave on the in-place {S, Q} image (jacobi_cross_sets_pw, default), 0 = the round-1
+// kernel -- WCT_JACOBI_PW, an A-B switch.  (A third variant was built and measured in round 2 and removed: only the
+// blocks on one side of the diagonal rotated, with mirrored stores, and Q carried by one extra wave, a row per lane in
+// registers -- 10 waves and 17 KB per pair problem, bit-compatible results; but that wave needs 4 NP dependent-free
+// FMAs + NP/2 LDS loads per set on ONE SIMD, ~700 cycles, longer than the whole set of the kernel below: Jacobi
+// 26.6 vs 23.8 ms per 32-pair step, 10.8 vs 9.5 ms at batch 1.)
+static int jacobi_pw_mode() {
   static const int pw = getenv("WCT_JACOBI_PW") ? atoi(getenv("WCT_JACOBI_PW")) : 1;
-  return pw != 0;
+  return pw;
 }
 
 // steps [step_begin, step_end) of one sweep: step -1 rotates the pairs inside each block, steps 0.. the cross pairs
@@ -1141,7 +1146,8 @@ template <int M2>
 static void jacobi_enqueue_steps(const JacobiGroup* grp, int ngrp, int C, int step_begin, int step_end) {
   constexpr int B = M2 / 2;
   const int nblk = C / B, npair = nblk / 2;
-  const bool pw = jacobi_use_pw();
+  const int mode = jacobi_pw_mode();
+  const bool pw = mode != 0;
   for (int step = step_begin; step < step_end; ++step)
     for (int g = 0; g < ngrp; ++g) {
       const JacobiGroup& G = grp[g];
