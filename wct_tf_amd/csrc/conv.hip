@@ -313,6 +313,9 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   if (force == 2) return launch_conv_cfg<32, 64, 4, 1>(a, s);
   if (force == 3) return launch_conv_cfg<16, 64, 4, 1>(a, s);
   if (force == 4) return launch_conv_cfg<8, 64, 2, 2>(a, s);
+  // (round 2: <32,64,2,2> and <16,128,1,4> -- the waves of a block split the output channels instead of the pixels,
+  //  halving / removing the redundant weight streams -- measured 593 vs 601 TFLOP/s on 64->64 @512^2 and 5-8 % slower on
+  //  the wide layers, profiles/r02_conv_cfg_sweep.txt: the weight streams are not what bounds these layers; removed)
   const long px16 = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.B;
   const long px32 = (long)cdiv(a.W, TW) * cdiv(a.H, 32) * a.B;
   if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) return launch_conv_cfg<16, 128, 2, 2>(a, s);
