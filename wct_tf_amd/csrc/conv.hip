@@ -13,11 +13,20 @@
 // so every lane ends up holding 4 consecutive output channels of one pixel and
 // the epilogue stores 8 B (fp16) / 16 B (fp32) per lane.
 #include "common.h"
+#include <stdio.h>
 
 // ---------------------------------------------------------------------------
 // generic 3x3 conv, Cin % 32 == 0, Cout % BN == 0
 // ---------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// Phase timing build (-DCONV_TS, tools/conv_phase_timing.sh): lane 0 of every block stamps s_memtime at its phase
+// boundaries; the launcher prints the per-launch means.  Compiled out of the product.
+#ifdef CONV_TS
+__device__ unsigned long long conv_ts[16384 * 10];
+#define TS(slot) do { if (threadIdx.x == 0) { const unsigned fl_ = blockIdx.x + gridDim.x * blockIdx.y; if (fl_ < 16384) conv_ts[fl_ * 10 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define TS(slot) do {} while (0)
+#endif
 constexpr int TW = 16;          // tile width in pixels (one MFMA B-fragment = 2 rows x 16)
 constexpr int PITCH = 20;       // patch row pitch in pixels (18 used; multiple of 4 keeps the swizzle aligned)
 constexpr int BK = 32;          // input channels per K-chunk
@@ -32,44 +41,67 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 // epilogue shared by the conv kernels: bias, ReLU, (2x2 max-pool), store
-template <int MT, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[NT][MT], int b, int y0, int x0, int n0,
-                                              int wm, int wn, int lane) {
+// acc register r of a 32x32 tile holds channel (r&3) + 8*(r>>2) + 4*(lane>>5) of pixel lane&31 (= tile row
+// (lane&31)>>4, column lane&15).  POOL: the 2x2/2 'same' max-pool that follows conv1_2 / conv2_2 / conv3_4 / conv4_4
+// (vgg_normalised.py:42) is taken here: an MFMA pixel tile is 2 rows x 16 columns starting at even coordinates, so
+// every pooling window lies inside one tile: max with lane^1 (column pair) and lane^16 (row pair); cells outside the
+// image are 0, neutral after the ReLU (ceil-mode edge).  OUT32: the fp32 feature tap (and the fp16 copy if p.y16).
+//
+// Written for instruction count (round 2): the round-1 epilogue tested p.pool / p.y32 / p.y16 / `inside` inside its
+// innermost loops and rebuilt 64-bit addresses per store -- ~2000 instructions and ~100 branches per wave, 10-13
+// thousand cycles per tile measured with s_memtime (profiles/r02_conv_phase_timing.txt: 30 % of a 64-channel tile's
+// residency).  Here the three variants are compile-time, the stores are buffer stores whose per-lane offset is
+// pushed out of range for pixels outside the image (the hardware drops them: no exec-mask branches), offsets within
+// a pixel are instruction immediates, ReLU runs on the packed fp16 pairs (rounding is monotonic and exact at 0, so
+// max-after-round == round-after-max), and the bias is not added here at all: the accumulators START from it (a bias
+// load between stores waits with vmcnt(0), i.e. for every store issued so far -- the round-1 epilogue made 8 MT
+// serial store round trips per tile -- and even hoisted above the stores its L2 latency sat on the critical path).
+template <int MT, int NT, bool POOL, bool OUT32>
+__device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)[NT][MT], int b, int y0, int x0, int n0,
+                                                int wm, int wn, int lane) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  constexpr int OOB = (int)0x80000000u;      // beyond num_records of every per-image buffer (< 2^31 bytes, checked at launch)
   const int frag_px = lane & 15;
   const int frag_py = (lane & 31) >> 4;
   const int kgrp = lane >> 5;
-  // --- epilogue: bias, ReLU, (2x2 max-pool), store.  acc register r of a 32x32 tile holds
-  // channel (r&3) + 8*(r>>2) + 4*(lane>>5) of pixel lane&31 (= tile row (lane&31)>>4, column lane&15).
-  // With p.pool the 2x2/2 'same' max-pool that follows conv1_2 / conv2_2 / conv3_4 / conv4_4
-  // (vgg_normalised.py:42) is taken here: an MFMA pixel tile is 2 rows x 16 columns starting at even
-  // coordinates, so every pooling window lies inside one tile: max with lane^1 (column pair) and
-  // lane^16 (row pair); cells outside the image are 0, neutral after the ReLU (ceil-mode edge).
-  const int Ho = p.pool ? (p.H + 1) / 2 : p.H, Wo = p.pool ? (p.W + 1) / 2 : p.W;
-  const size_t out_base = (size_t)b * Ho * Wo;
+  const int Ho = POOL ? (p.H + 1) / 2 : p.H, Wo = POOL ? (p.W + 1) / 2 : p.W;
+  const unsigned img_elems = (unsigned)Ho * Wo * p.Cout;
+  // one buffer per image and precision; a null output gets an empty buffer: all its stores are dropped
+  const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.y16 ? p.y16 + (size_t)b * img_elems : nullptr), 0, p.y16 ? img_elems * 2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r32 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(OUT32 && p.y32 ? p.y32 + (size_t)b * img_elems : nullptr), 0, OUT32 && p.y32 ? img_elems * 4 : 0, 0x00020000);
+  const float lo1 = p.relu ? 0.f : -__builtin_inff();
+  const h2 lo2 = {(half_t)lo1, (half_t)lo1};
+  const int ox = x0 + frag_px;
+  const int chan = n0 + wn * NT * 32;        // first channel of this wave; + nt*32 (+ 8 rq / 16 m) are immediates
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int oy = y0 + (wm * MT + mt) * 2 + frag_py;
-    const int ox = x0 + frag_px;
-    const bool in_img = oy < p.H && ox < p.W;
-    const bool inside = p.pool ? (in_img && frag_py == 0 && (frag_px & 1) == 0) : in_img;
-    const size_t pix = out_base + (p.pool ? (size_t)(oy >> 1) * Wo + (ox >> 1) : (size_t)oy * p.W + ox);
+    const bool in_img = (oy < p.H) & (ox < p.W);
+    const bool inside = POOL ? (in_img & (frag_py == 0) & ((frag_px & 1) == 0)) : in_img;
+    const int pix = POOL ? (oy >> 1) * Wo + (ox >> 1) : oy * p.W + ox;
+    const int off16 = inside ? (pix * p.Cout + chan + 8 * kgrp) * 2 : OOB;
+    const int off32 = inside ? (pix * p.Cout + chan + 4 * kgrp) * 4 : OOB;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       unsigned pk[4][2];                      // fp16 x4 of each register quad, packed
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const int co = n0 + (wn * NT + nt) * 32 + 8 * rq + 4 * kgrp;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
         f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float t = acc[nt][mt][rq * 4 + j] + bv[j];
-          v[j] = p.relu ? fmaxf(t, 0.f) : t;
+        for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][rq * 4 + j];        // bias included: the accumulators start from it
+        if (OUT32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo1);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r32, off32 + (nt * 32 + 8 * rq) * 4, 0, 0);
         }
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2 lo = {(half_t)v[0], (half_t)v[1]}, hi = {(half_t)v[2], (half_t)v[3]};
-        if (p.pool) {
-          // on the packed fp16 pairs (rounding is monotonic, so max-after-round == round-after-max):
+        if (!OUT32) {
+          lo = __builtin_elementwise_max(lo, lo2);
+          hi = __builtin_elementwise_max(hi, lo2);
+        }
+        if (POOL) {
           // column pair by DPP quad_perm(1,0,3,2), row pair by ds_swizzle xor 16
           const h2 zero = {(half_t)0.f, (half_t)0.f};
           h2 q[2] = {in_img ? lo : zero, in_img ? hi : zero};
@@ -83,27 +115,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[N
             q[d] = __builtin_elementwise_max(q[d], o);
           }
           lo = q[0]; hi = q[1];
-        } else if (inside && p.y32) {
-          *reinterpret_cast<f32x4*>(p.y32 + pix * p.Cout + co) = v;
         }
         pk[rq][0] = __builtin_bit_cast(unsigned, lo);
         pk[rq][1] = __builtin_bit_cast(unsigned, hi);
       }
-      if (p.y16) {
-        // a lane holds channels 8rq+4kgrp..+3 of its pixel: the two half-waves own interleaved 8-byte
-        // pieces.  One v_permlane32_swap per dword pairs quad 2m with quad 2m+1 so that the lower half
-        // stores channels 16m..16m+7 and the upper half 16m+8..16m+15: 16-byte stores, half as many.
+      // a lane holds channels 8rq+4kgrp..+3 of its pixel: the two half-waves own interleaved 8-byte pieces.  One
+      // v_permlane32_swap per dword pairs quad 2m with quad 2m+1 so that the lower half stores channels 16m..16m+7
+      // and the upper half 16m+8..16m+15: 16-byte stores, half as many.
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * m][0], pk[2 * m + 1][0], false, false);
-          auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * m][1], pk[2 * m + 1][1], false, false);
-          u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
-          const int co = n0 + (wn * NT + nt) * 32 + 16 * m + 8 * kgrp;
-          if (inside) *reinterpret_cast<u32x4*>(p.y16 + pix * p.Cout + co) = o;
-        }
+      for (int m = 0; m < 2; ++m) {
+        auto sx = __builtin_amdgcn_permlane32_swap(pk[2 * m][0], pk[2 * m + 1][0], false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(pk[2 * m][1], pk[2 * m + 1][1], false, false);
+        u32x4 o = {sx[0], sy[0], sx[1], sy[1]};
+        __builtin_amdgcn_raw_buffer_store_b128(o, r16, off16 + (nt * 32 + 16 * m) * 2, 0, 0);
       }
     }
   }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[NT][MT], int b, int y0, int x0, int n0,
+                                              int wm, int wn, int lane) {
+  if (p.pool) conv_epilogue_t<MT, NT, true, false>(p, acc, b, y0, x0, n0, wm, wn, lane);
+  else if (p.y32) conv_epilogue_t<MT, NT, false, true>(p, acc, b, y0, x0, n0, wm, wn, lane);
+  else conv_epilogue_t<MT, NT, false, false>(p, acc, b, y0, x0, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -140,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
+  TS(8);
 
   int bid = blockIdx.x;
   const int ntile = bid % n_tiles;
@@ -196,13 +232,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7FFFFFFF, 0x00020000);
 
+  // the accumulators start from the bias: register r of tile (nt, .) holds channel (r&3) + 8*(r>>2) + 4*kgrp of the
+  // wave's 32-channel group nt (the loads travel with the first patch; the epilogue adds nothing)
   f32x16 acc[NT][MT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int rq = 0; rq < 4; ++rq) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + (wn * NT + nt) * 32 + 8 * rq + 4 * kgrp);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[nt][mt][rq * 4 + j] = bv[j];
+    }
 
   const int n_chunks = p.Cin / BK;           // even: Cin is a multiple of 64 on this path
   u32x4 patch_regs[PATCH_PER_THREAD];
@@ -232,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
       *reinterpret_cast<u32x4*>(smem + patch_dst[i]) = patch_regs[i];
   };
 
+  TS(1);
   load_patch(0);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -240,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
       wf[0][nt][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wfrag[nt] + ks * 1024, 0, 0));
   store_patch();
   __syncthreads();
+  TS(2);
   read_group(bf[0], 0, 0, 0);
 
 #pragma unroll 1
@@ -286,7 +330,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  TS(5);
   conv_epilogue<MT, NT>(p, acc, b, y0, x0, n0, wm, wn, lane);
+  TS(6);
+#ifdef CONV_TS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TS(7);
+#endif
 }
 
 template <int TH, int BN, int WM, int WN>
@@ -297,6 +347,25 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const size_t lds = (size_t)PH * PITCH * 64 + 4096;
   dim3 grid(tiles_x * tiles_y * n_tiles, a.B);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
+#ifdef CONV_TS
+  if (a.B >= 8) {
+    static int nlaunch = 0;
+    ++nlaunch;
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[16384 * 10];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(conv_ts), sizeof(host));
+    const int nb = (int)(grid.x * grid.y < 16384 ? grid.x * grid.y : 16384);
+    double sum[6] = {0};       // slots: 8 entry, 1 addresses ready, 2 first patch in LDS, 5 taps done, 6 epilogue issued, 7 stores drained
+    for (int i = 0; i < nb; ++i) {
+      const unsigned long long* h = host + (size_t)i * 10;
+      sum[0] += (double)(h[1] - h[8]); sum[1] += (double)(h[2] - h[1]); sum[2] += (double)(h[5] - h[2]);
+      sum[3] += (double)(h[6] - h[5]); sum[4] += (double)(h[7] - h[6]); sum[5] += (double)(h[7] - h[8]);
+    }
+    fprintf(stderr, "TS launch %d <%d,%d,%d,%d> Cin %d Cout %d H %d up %d pool %d y32 %d blocks %d: setup %.0f load0 %.0f mainloop %.0f epilogue %.0f drain %.0f total %.0f\n",
+            nlaunch, TH, BN, WM, WN, a.Cin, a.Cout, a.H, a.upsample, a.pool, a.y32 != nullptr, nb,
+            sum[0] / nb, sum[1] / nb, sum[2] / nb, sum[3] / nb, sum[4] / nb, sum[5] / nb);
+  }
+#endif
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
@@ -306,6 +375,7 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK(!a.upsample || (a.H % 2 == 0 && a.W % 2 == 0));
   // one image's activations are addressed with 32-bit byte offsets (buffer loads)
   ARG_CHECK((size_t)a.H * a.W * a.Cin * 2 < ((size_t)1 << 31));
+  ARG_CHECK((size_t)a.H * a.W * a.Cout * (a.y32 ? 4 : 2) < ((size_t)1 << 31));     // per-image output buffers (epilogue)
   ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
   static const int force = getenv("WCT_CONV_CFG") ? atoi(getenv("WCT_CONV_CFG")) : 0;   // tuning switch
