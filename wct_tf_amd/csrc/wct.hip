@@ -799,7 +799,7 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
   block_pair(g, step, nblk, bi, bj);
   float* Am = A + (size_t)m * C * C;
   float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
-  float my_off = 0.f, my_sig = 0.f;
+  float my_off = 0.f, my_sig = 0.f, my_dm = 0.f;
   const float floor_m = st[m].floor;
   bool finite = true;
   if (PW && step >= 0) {
@@ -809,6 +809,7 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
       v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
       v[1] = r == c ? 1.f : 0.f;
       finite &= fabsf(v[0]) <= 3.0e38f;
+      if (r == c) my_dm = fmaxf(my_dm, fabsf(v[0]));
       SQ[e] = v;
     }
     __syncthreads();
@@ -822,6 +823,7 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
       v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
       v[1] = r == c ? 1.f : 0.f;
       finite &= fabsf(v[0]) <= 3.0e38f;
+      if (r == c) my_dm = fmaxf(my_dm, fabsf(v[0]));
       SQ[r * PITCH + c] = v;
     }
     __syncthreads();
@@ -834,16 +836,14 @@ __global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A
   for (int o = 32; o > 0; o >>= 1) {
     my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
     my_sig = fmaxf(my_sig, __shfl_xor(my_sig, o, 64));
+    my_dm = fmaxf(my_dm, __shfl_xor(my_dm, o, 64));
   }
   if ((tid & 63) == 0) {
     if (my_off > 0.f) atomicMax(&st[m].offmax, __float_as_uint(my_off));
     if (my_sig > 0.f) atomicMax(&st[m].offsig, __float_as_uint(my_sig));
-  }
-  if (tid < 64) {                               // largest diagonal of the rotated pair problem -> next sweep's floor
-    float dm = 0.f;
-    for (int i = tid; i < M2; i += 64) dm = fmaxf(dm, fabsf(Am[(size_t)pair_index<B>(i, bi, bj) * C + pair_index<B>(i, bi, bj)]));
-    for (int o = 32; o > 0; o >>= 1) dm = fmaxf(dm, __shfl_xor(dm, o, 64));
-    if (tid == 0 && dm < 3.0e38f) atomicMax(&st[m].dmax, __float_as_uint(dm));
+    // largest diagonal of the pair problem as loaded -> next sweep's floor (taken from the values already in registers:
+    // re-reading the diagonal from global memory put one more dependent memory round trip at the end of every block)
+    if (my_dm > 0.f && my_dm < 3.0e38f) atomicMax(&st[m].dmax, __float_as_uint(my_dm));
   }
 }
 
