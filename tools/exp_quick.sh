@@ -3,7 +3,6 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/exp_quick.txt
 : > $O
 B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-latency"
-for i in 1 2; do
 timeout 300 $B 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
@@ -12,6 +11,5 @@ for l in sys.stdin:
         d = json.loads(l); print('fps %.1f ms/step %.2f' % (d['value'], d['ms_per_step']), {k: round(v, 2) for k, v in d['breakdown_ms_per_step'].items()}, 'conv frac %.3f' % d['roofline']['frac'])
     elif l and 'amdgpu.ids' not in l: print(l[:300])
 " >> $O
-done
-timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "conv" 2>&1 | tail -3 >> $O
+timeout 600 python -m pytest tests/test_gpu_train.py tests/test_gpu_ops.py -x -q -m gpu -k "train or conv" 2>&1 | tail -3 >> $O
 cat $O

@@ -53,12 +53,14 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // residency).  Here the three variants are compile-time, the stores are buffer stores whose per-lane offset is
 // pushed out of range for pixels outside the image (the hardware drops them: no exec-mask branches), offsets within
 // a pixel are instruction immediates, ReLU runs on the packed fp16 pairs (rounding is monotonic and exact at 0, so
-// max-after-round == round-after-max), and the bias is not added here at all: the accumulators START from it (a bias
-// load between stores waits with vmcnt(0), i.e. for every store issued so far -- the round-1 epilogue made 8 MT
-// serial store round trips per tile -- and even hoisted above the stores its L2 latency sat on the critical path).
+// max-after-round == round-after-max), and the bias comes from a copy the block parked in LDS at its start (a bias
+// load from global memory between stores waits with vmcnt(0), i.e. for every store issued so far -- the round-1
+// epilogue made 8 MT serial store round trips per tile -- and even hoisted above the stores its L2 latency sat on the
+// critical path).  The bias is still added LAST, after the sum over taps and channels: starting the accumulators
+// from it saved the 128 adds but moved fp32 roundings, and with them a few fp16 roundings of the activations.
 template <int MT, int NT, bool POOL, bool OUT32>
 __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)[NT][MT], int b, int y0, int x0, int n0,
-                                                int wm, int wn, int lane) {
+                                                int wm, int wn, int lane, const unsigned char* bias_lds) {
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   constexpr int OOB = (int)0x80000000u;      // beyond num_records of every per-image buffer (< 2^31 bytes, checked at launch)
   const int frag_px = lane & 15;
@@ -71,6 +73,12 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)
       (void*)(p.y16 ? p.y16 + (size_t)b * img_elems : nullptr), 0, p.y16 ? img_elems * 2 : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t r32 = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(OUT32 && p.y32 ? p.y32 + (size_t)b * img_elems : nullptr), 0, OUT32 && p.y32 ? img_elems * 4 : 0, 0x00020000);
+  f32x4 bvs[NT][4];                          // this lane's bias values, from the block's LDS copy
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+      bvs[nt][rq] = *reinterpret_cast<const f32x4*>(bias_lds + ((wn * NT + nt) * 32 + 8 * rq + 4 * kgrp) * 4);
   const float lo1 = p.relu ? 0.f : -__builtin_inff();
   const h2 lo2 = {(half_t)lo1, (half_t)lo1};
   const int ox = x0 + frag_px;
@@ -90,7 +98,7 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)
       for (int rq = 0; rq < 4; ++rq) {
         f32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][rq * 4 + j];        // bias included: the accumulators start from it
+        for (int j = 0; j < 4; ++j) v[j] = acc[nt][mt][rq * 4 + j] + bvs[nt][rq][j];
         if (OUT32) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo1);
@@ -135,10 +143,10 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)
 
 template <int MT, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[NT][MT], int b, int y0, int x0, int n0,
-                                              int wm, int wn, int lane) {
-  if (p.pool) conv_epilogue_t<MT, NT, true, false>(p, acc, b, y0, x0, n0, wm, wn, lane);
-  else if (p.y32) conv_epilogue_t<MT, NT, false, true>(p, acc, b, y0, x0, n0, wm, wn, lane);
-  else conv_epilogue_t<MT, NT, false, false>(p, acc, b, y0, x0, n0, wm, wn, lane);
+                                              int wm, int wn, int lane, const unsigned char* bias_lds) {
+  if (p.pool) conv_epilogue_t<MT, NT, true, false>(p, acc, b, y0, x0, n0, wm, wn, lane, bias_lds);
+  else if (p.y32) conv_epilogue_t<MT, NT, false, true>(p, acc, b, y0, x0, n0, wm, wn, lane, bias_lds);
+  else conv_epilogue_t<MT, NT, false, false>(p, acc, b, y0, x0, n0, wm, wn, lane, bias_lds);
 }
 
 // ---------------------------------------------------------------------------
@@ -164,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
   constexpr int PATCH_PER_THREAD = (PATCH_ITEMS + 255) / 256;
   constexpr int PATCH_BYTES = PH * PITCH * 64;
   constexpr int DUMP_OFF = PATCH_BYTES;
+  constexpr int BIAS_OFF = PATCH_BYTES + 4096;
   // tap at which the next K-chunk's patch loads are issued (their registers are live from there to the
   // chunk boundary only); the tall tile has no registers to spare and loads at the boundary
   constexpr int PF_TAP = TH <= 16 ? 6 : 9;
@@ -232,19 +241,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7FFFFFFF, 0x00020000);
 
-  // the accumulators start from the bias: register r of tile (nt, .) holds channel (r&3) + 8*(r>>2) + 4*kgrp of the
-  // wave's 32-channel group nt (the loads travel with the first patch; the epilogue adds nothing)
   f32x16 acc[NT][MT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + (wn * NT + nt) * 32 + 8 * rq + 4 * kgrp);
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[nt][mt][rq * 4 + j] = bv[j];
-    }
+      for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+  // the block's bias values -> LDS (read back by the epilogue; visible after the first patch barrier)
+  if (tid < BN / 4)
+    *reinterpret_cast<f32x4*>(smem + BIAS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias + n0 + tid * 4);
 
   const int n_chunks = p.Cin / BK;           // even: Cin is a multiple of 64 on this path
   u32x4 patch_regs[PATCH_PER_THREAD];
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int ti
     }
   }
   TS(5);
-  conv_epilogue<MT, NT>(p, acc, b, y0, x0, n0, wm, wn, lane);
+  conv_epilogue<MT, NT>(p, acc, b, y0, x0, n0, wm, wn, lane, smem + BIAS_OFF);
   TS(6);
 #ifdef CONV_TS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,7 +350,7 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
   const int n_tiles = a.Cout / BN;
   constexpr int PH = TH + 2;
-  const size_t lds = (size_t)PH * PITCH * 64 + 4096;
+  const size_t lds = (size_t)PH * PITCH * 64 + 4096 + BN * sizeof(float);     // patch, dump slots, bias
   dim3 grid(tiles_x * tiles_y * n_tiles, a.B);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
 #ifdef CONV_TS
