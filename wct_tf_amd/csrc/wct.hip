@@ -237,12 +237,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   // ---- epilogue: reg r of a tile = row (r&3)+8*(r>>2)+4*(lane>>5), col lane&31
   float* o32 = p.out32 ? p.out32 + batch * p.s_out + (size_t)split * p.out_split_stride : nullptr;
   half_t* o16 = p.out16 ? p.out16 + batch * p.s_out : nullptr;
+  float biasv[TN];                               // fetched before the first store (see conv_epilogue_t)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
+    biasv[j] = (p.bias_n && gn < p.N) ? p.bias_n[gn] : 0.f;
+  }
+  // ... and handed to the store loop as plain register values: hipcc otherwise re-issues `s_waitcnt vmcnt(0)` at the first
+  // use in every predicated block, and each of those waits for all stores before it (64 serial round trips per thread)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(biasv[j]));
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int gn = n0 + (wn * TN + j) * 32 + (lane & 31);
-      const float bias = (p.bias_n && gn < p.N) ? p.bias_n[gn] : 0.f;
+      const float bias = biasv[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1487,6 +1497,17 @@ __global__ __launch_bounds__(256, 2) void apply_f16x2_kernel(ApplyArgs p) {
   const float inv = 1.f / (sx * sM);
   const float* bias = p.bias + (size_t)pair * C;
   const int kgrp = lane >> 5;
+  // this lane's bias values, fetched before the first store (a load issued between the stores waits with vmcnt(0),
+  // i.e. for every store issued so far: see conv_epilogue_t)
+  f32x4 bvs[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int co = c0 + (wm * TM + i) * 32 + 8 * rq + 4 * kgrp;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      bvs[i][rq] = co < C ? *reinterpret_cast<const f32x4*>(bias + co) : z;
+    }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -1499,8 +1520,7 @@ __global__ __launch_bounds__(256, 2) void apply_f16x2_kernel(ApplyArgs p) {
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int co = cb + 8 * rq + 4 * kgrp;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (co < C) bv = *reinterpret_cast<const f32x4*>(bias + co);
+        const f32x4 bv = bvs[i][rq];
         f32x4 v;
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = acc[i][j][rq * 4 + q] * inv + bv[q];
