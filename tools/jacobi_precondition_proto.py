@@ -86,23 +86,24 @@ def pivoted_cholesky(A):
         d[k + 1:] -= L[k + 1:, k] ** 2
     return L, perm
 
-z = np.load(sys.argv[1] if len(sys.argv) > 1 else "/tmp/wct_levels.npz")     # level features: tools/wct_tol_probe.py writes this cache
-for i in (0, 1, 2):
-    for side in ('fc', 'fs'):
-        f = z['%s%d' % (side, i)]
-        C = f.shape[-1]
-        X = f.reshape(-1, C).astype(np.float64)
-        X = X - X.mean(0)
-        A = (X.T @ X) / (X.shape[0] - 1)
-        ev = np.linalg.eigvalsh(A)
-        print('level %d %s: C=%d N=%d  eig max %.3e min %.3e  kept(>1e-5) %d' % (i, side, C, X.shape[0], ev[-1], ev[0], (ev > 1e-5).sum()), flush=True)
-        t0 = time.time()
-        run(A, 'plain two-sided Jacobi')
-        d = np.argsort(-np.diag(A))
-        run(A[np.ix_(d, d)], 'diagonal-sorted')
-        L, perm = pivoted_cholesky(A)
-        A1 = L.T @ L
-        run(A1, 'Cholesky-LR x1 (L^T L)')
-        L2, _ = pivoted_cholesky(A1)
-        run(L2.T @ L2, 'Cholesky-LR x2')
-        print('   (%.0f s)' % (time.time() - t0), flush=True)
+if __name__ == '__main__':
+    z = np.load(sys.argv[1] if len(sys.argv) > 1 else "/tmp/wct_levels.npz")     # level features: tools/wct_tol_probe.py writes this cache
+    for i in (0, 1, 2):
+        for side in ('fc', 'fs'):
+            f = z['%s%d' % (side, i)]
+            C = f.shape[-1]
+            X = f.reshape(-1, C).astype(np.float64)
+            X = X - X.mean(0)
+            A = (X.T @ X) / (X.shape[0] - 1)
+            ev = np.linalg.eigvalsh(A)
+            print('level %d %s: C=%d N=%d  eig max %.3e min %.3e  kept(>1e-5) %d' % (i, side, C, X.shape[0], ev[-1], ev[0], (ev > 1e-5).sum()), flush=True)
+            t0 = time.time()
+            run(A, 'plain two-sided Jacobi')
+            d = np.argsort(-np.diag(A))
+            run(A[np.ix_(d, d)], 'diagonal-sorted')
+            L, perm = pivoted_cholesky(A)
+            A1 = L.T @ L
+            run(A1, 'Cholesky-LR x1 (L^T L)')
+            L2, _ = pivoted_cholesky(A1)
+            run(L2.T @ L2, 'Cholesky-LR x2')
+            print('   (%.0f s)' % (time.time() - t0), flush=True)
