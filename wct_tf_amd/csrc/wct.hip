@@ -1095,6 +1095,26 @@ __global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int n
   st[m].dmax = 0u;
 }
 
+// The same residual test in the MIDDLE of a sweep (tol_fn callers only): near the end the residual halves every third
+// of a sweep (tools/jacobi_block_order_proto.py), so a matrix that a full sweep would take 10x below the stop threshold
+// is usually below it half a sweep earlier; its remaining launches of the sweep turn into no-ops.  Touches nothing but
+// `done`, r2 / r2l and the sweep count (the half sweep counts as one).
+__global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, int nmat, float tol_fn) {
+  const int m = threadIdx.x;
+  if (m >= nmat || st[m].done) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < JACOBI_RESID_CHUNKS; ++c)
+    for (int j = 0; j < 4; ++j) v[j] += partial[((size_t)m * JACOBI_RESID_CHUNKS + c) * 4 + j];
+  const float r2 = v[0] / fmaxf(v[1], 1.f);
+  if (st[m].offmax < 0x7f800000u && r2 < tol_fn * tol_fn) {       // finite so far and converged
+    st[m].r2 = r2;
+    st[m].r2l = v[2] / fmaxf(v[3], 1.f);
+    st[m].last_sig = st[m].offsig;
+    st[m].sweeps += 1;
+    st[m].done = 1;
+  }
+}
+
 // End of a solve.  A matrix still rotating after the last allowed sweep has FAILED only if its last sweep still saw a
 // significant pair above the tolerance; noise-level pairs alone (numerical null space of a rank-deficient covariance:
 // N < C pixels, dead or duplicated channels) never settle and do not matter.
@@ -1196,6 +1216,10 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   const int half = -1 + nblk / 2;                 // steps [-1, half) | [half, nblk - 1)
   const int max_sweeps = jacobi_max_sweeps();
   static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
+  // first sweep with a residual test in its middle as well (-1: never); before the fourth sweep no matrix of this size class
+  // is anywhere near the threshold, and below 8 blocks a half sweep is too short to be worth a measurement
+  static const int mid_env = getenv("WCT_JACOBI_MID") ? atoi(getenv("WCT_JACOBI_MID")) : 3;
+  const int mid_from = nblk >= 8 ? mid_env : -1;
   JacobiHost* host = jacobi_host();
   for (int g = 0; g < ngrp; ++g)
     hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].V, grp[g].st, C,
@@ -1212,6 +1236,12 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
       pending = false;
       if (all) break;
     }
+    if (mid_from >= 0 && sweep >= mid_from)
+      for (int g = 0; g < ngrp; ++g)
+        if (grp[g].tol_fn > 0.f) {
+          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C);
+          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn);
+        }
     jacobi_enqueue_steps<M2>(grp, ngrp, C, half, nblk - 1);
     for (int g = 0; g < ngrp; ++g) {
       hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C);
