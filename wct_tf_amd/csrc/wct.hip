@@ -11,6 +11,7 @@
 //                     blend and re-centring folded into M and b)
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 // ---------------------------------------------------------------------------
@@ -482,7 +483,7 @@ struct JacobiState {
   unsigned int dmax;     // max |a_ii| seen by this sweep's pair problems (float bits)
   float r2;              // strict residual measure of the last completed sweep (jacobi_resid_kernel), -1 before the first
   float r2l;             // the lenient one (what the final status is judged by)
-  int pad;
+  int pad;               // look-ahead path: the buffer (0: A, 1: the second one) that held the matrix when it was declared done
 };
 constexpr int JACOBI_RESID_CHUNKS = 16;
 constexpr float JACOBI_SIG_FLOOR = 1e-4f;
@@ -987,6 +988,300 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
   }
 }
 
+// ---------------------------------------------------------------------------
+// K5, look-ahead launches (round 3).  The serial chain of a solve used to be  D(s) -> U(s) -> D(s+1) -> ...  (pair
+// problems, then the tile update that needs their rotations, then the next pair problems that need the updated
+// tiles): two dependent launches per outer step, the latency-bound pair kernel idle while the tile update runs and
+// vice versa.  Here ONE launch carries  { D(s), U(s-1) }:
+//   * D(s) does not wait for U(s-1).  Its 2B x 2B pair problem (blocks bi, bj) is assembled from the rotated images
+//     D(s-1) left behind (Sbuf: they ARE the diagonal tiles after U(s-1)) and ONE off-diagonal B x B block it
+//     computes itself -- crit = Q_g1[:, h1]^T . P_old[tile g1, g2] . Q_g2[:, h2], with (g1, h1) / (g2, h2) the pair and
+//     half that held bi / bj at step s-1 -- from the matrix state BEFORE U(s-1) and the rotations of step s-1;
+//   * U(s-1) reads P_old and writes every tile into the other buffer P_new (off-diagonal tiles g < h computed and
+//     mirrored, diagonal tiles copied from Sbuf), so D(s) can read P_old while it runs; V is updated in place.
+// Both parts use the whole block (M2/2)^2 threads = (M2/16)^2 waves, one 16x16 output tile of v_mfma_f32_16x16x4_f32
+// per wave.  The chain of a solve becomes D -> D -> D ...; the tile updates run beside it.
+// Data routing checked against the plain sequence in tools/jacobi_lookahead_proto.py.
+// ---------------------------------------------------------------------------
+struct JacobiFusedArgs {
+  const float* Pr;      // [nmat][C][C] state the U part reads and the D part takes its look-ahead block from
+  float* Pw;            // [nmat][C][C] state the U part writes
+  float* V;             // [nmat][C][C] eigenvector accumulation, in place
+  const float* Qr; const float* Sr;   // [nmat][npair][M2*M2] rotations / rotated pair problems of step_u
+  float* Qw; float* Sw;               // ... written by the D part (step_d)
+  JacobiState* st;
+  int C, nmat;
+  int step_d, step_u;   // outer step of the pair problems / of the tile update (= the step before step_d)
+  int has_d, has_u;
+  int first;            // the D part loads its pair problems straight from Pr (nothing is pending on it)
+};
+
+// inverse of block_pair: pair index and half (0: first block, 1: second) of block b at outer step `step`
+__device__ __forceinline__ void block_locate(int b, int step, int nblk, int& g, int& half) {
+  if (step < 0) { g = b >> 1; half = b & 1; return; }
+  int pos = 0;
+  if (b != 0) {
+    int v = b - 1 - step;                       // step <= nblk - 2: one wrap is enough
+    if (v < 0) v += nblk - 1;
+    pos = v + 1;
+  }
+  const int npair = nblk >> 1;
+  if (pos < npair) { g = pos; half = 0; } else { g = nblk - 1 - pos; half = 1; }
+}
+
+template <int M2>
+static size_t jacobi_fused_lds(int has_d, int has_u, int first, int step_d) {
+  constexpr int B = M2 / 2;
+  size_t need = 0;
+  if (has_d) {
+    if (step_d < 0) need = jacobi_diag_lds<M2>(-1, true);                               // intra sets: two images
+    else {
+      need = jacobi_diag_lds<M2>(0, true);
+      if (!first) need = std::max(need, (size_t)(M2 * (M2 + 1) + 2 * M2 * (B + 1) + B * (M2 + 1)) * sizeof(float));
+    }
+  }
+  if (has_u) need = std::max(need, (size_t)3 * M2 * (M2 + 1) * sizeof(float));
+  return need;
+}
+
+template <int M2>
+__device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, int g, float* jsm) {
+  constexpr int B = M2 / 2, NT = B * B, KB = 1, NW = M2 / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = p.C, nblk = C / B, npair = nblk / 2;
+  f32x2* SQ = reinterpret_cast<f32x2*>(jsm);
+  int bi, bj;
+  block_pair(g, p.step_d, nblk, bi, bj);
+  const float floor_m = p.st[m].floor;
+  float my_off = 0.f, my_sig = 0.f, my_dm = 0.f;
+  bool finite = true;
+  float* Qo = p.Qw + ((size_t)m * npair + g) * (M2 * M2);
+  float* So = p.Sw + ((size_t)m * npair + g) * (M2 * M2);
+  if (p.first) {
+    const float* Am = p.Pr + (size_t)m * C * C;
+    const int PITCH = p.step_d >= 0 ? M2 : M2 + 1;
+    for (int e = tid; e < M2 * M2; e += NT) {
+      const int r = e / M2, c = e % M2;
+      f32x2 v;
+      v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
+      v[1] = r == c ? 1.f : 0.f;
+      finite &= fabsf(v[0]) <= 3.0e38f;
+      if (r == c) my_dm = fmaxf(my_dm, fabsf(v[0]));
+      SQ[r * PITCH + c] = v;
+    }
+    __syncthreads();
+  } else {
+    // ---- look-ahead assembly (cross steps only: a segment never starts behind an intra step)
+    int g1, h1, g2, h2;
+    block_locate(bi, p.step_u, nblk, g1, h1);
+    block_locate(bj, p.step_u, nblk, g2, h2);
+    const float* S1 = p.Sr + ((size_t)m * npair + g1) * (M2 * M2);
+    const float* S2 = p.Sr + ((size_t)m * npair + g2) * (M2 * M2);
+    const bool same = g1 == g2;
+    // this thread's four image elements that come out of the previous images (requested before the staging loads)
+    float sv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * NT, r = e / M2, c = e % M2;
+      const bool rlo = r < B, clo = c < B;
+      const float* src = rlo ? S1 : S2;
+      const int rr = (rlo ? h1 : h2) * B + (rlo ? r : r - B);
+      const int cc = (clo ? h1 : h2) * B + (clo ? c : c - B);
+      sv[i] = (rlo == clo || same) ? src[rr * M2 + cc] : 0.f;
+    }
+    f32x4 crit = {0.f, 0.f, 0.f, 0.f};
+    if (!same) {
+      float* Xs = jsm;                              // [M2][M2 + 1]  tile (g1, g2) of the state before U(step_u)
+      float* Q1s = Xs + M2 * (M2 + 1);              // [M2][B + 1]   columns h1 of Q_g1
+      float* Q2s = Q1s + M2 * (B + 1);              // [M2][B + 1]   columns h2 of Q_g2
+      float* Ws = Q2s + M2 * (B + 1);               // [B][M2 + 1]   Q_g1[:, h1]^T X
+      int b1i, b1j, b2i, b2j;
+      block_pair(g1, p.step_u, nblk, b1i, b1j);
+      block_pair(g2, p.step_u, nblk, b2i, b2j);
+      const float* Pm = p.Pr + (size_t)m * C * C;
+      {
+        const int e = tid * 4, r = e / M2, c = e % M2;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(Pm + (size_t)pair_index<B>(r, b1i, b1j) * C + pair_index<B>(c, b2i, b2j));
+        // Q columns: M2 x B floats per side = NT / 2 float4; first half of the block fetches Q_g1, second half Q_g2
+        const int t2 = tid < NT / 2 ? tid : tid - NT / 2;
+        const int qe = t2 * 4, qr = qe / B, qc = qe % B;
+        const float* Qsrc = p.Qr + ((size_t)m * npair + (tid < NT / 2 ? g1 : g2)) * (M2 * M2) + qr * M2 + (tid < NT / 2 ? h1 : h2) * B + qc;
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(Qsrc);
+        float* Qdst = (tid < NT / 2 ? Q1s : Q2s) + qr * (B + 1) + qc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Xs[r * (M2 + 1) + c + j] = xv[j]; Qdst[j] = qv[j]; }
+      }
+      __syncthreads();
+      const int li = lane & 15, lq = lane >> 4;
+      if (wave < (B / 16) * NW) {                   // W = Q_g1[:, h1]^T X   (B x M2)
+        const int tr = wave / NW, tj = wave % NW;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int kk = 0; kk < M2; kk += 4)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Q1s[(kk + lq) * (B + 1) + 16 * tr + li], Xs[(kk + lq) * (M2 + 1) + 16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ws[(16 * tr + 4 * lq + r) * (M2 + 1) + 16 * tj + li] = acc[r];
+      }
+      __syncthreads();
+      if (wave < (B / 16) * (B / 16)) {             // crit = W Q_g2[:, h2]   (B x B)
+        const int tr = wave / (B / 16), tc = wave % (B / 16);
+#pragma unroll 4
+        for (int kk = 0; kk < M2; kk += 4)
+          crit = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * tr + li) * (M2 + 1) + kk + lq], Q2s[(kk + lq) * (B + 1) + 16 * tc + li], crit, 0, 0, 0);
+      }
+      __syncthreads();                              // the staging area becomes the image
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * NT, r = e / M2, c = e % M2;
+      if ((r < B) == (c < B) || same) {
+        f32x2 v; v[0] = sv[i]; v[1] = r == c ? 1.f : 0.f;
+        SQ[e] = v;
+      }
+    }
+    if (!same && wave < (B / 16) * (B / 16)) {
+      const int tr = wave / (B / 16), tc = wave % (B / 16), li = lane & 15, lq = lane >> 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tr + 4 * lq + r, col = B + 16 * tc + li;
+        f32x2 v; v[0] = crit[r]; v[1] = 0.f;
+        SQ[row * M2 + col] = v;
+        SQ[col * M2 + row] = v;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < M2 * M2; e += NT) {
+      const float v = SQ[e][0];
+      finite &= fabsf(v) <= 3.0e38f;
+      if (e / M2 == e % M2) my_dm = fmaxf(my_dm, fabsf(v));
+    }
+  }
+  if (p.step_d >= 0) {
+    jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig);
+    for (int e = tid; e < M2 * M2; e += NT) { const f32x2 v = SQ[e]; So[e] = v[0]; Qo[e] = v[1]; }
+  } else {
+    constexpr int PITCH = M2 + 1;
+    float* DO = jsm + 4 * M2 * PITCH;
+    const int cur = jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, floor_m, my_off, my_sig);
+    for (int e = tid; e < M2 * M2; e += NT) {
+      const f32x2 v = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)];
+      So[e] = v[0]; Qo[e] = v[1];
+    }
+  }
+  if (!finite) my_off = __builtin_inff();
+  for (int o = 32; o > 0; o >>= 1) {
+    my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
+    my_sig = fmaxf(my_sig, __shfl_xor(my_sig, o, 64));
+    my_dm = fmaxf(my_dm, __shfl_xor(my_dm, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    if (my_off > 0.f) atomicMax(&p.st[m].offmax, __float_as_uint(my_off));
+    if (my_sig > 0.f) atomicMax(&p.st[m].offsig, __float_as_uint(my_sig));
+    if (my_dm > 0.f && my_dm < 3.0e38f) atomicMax(&p.st[m].dmax, __float_as_uint(my_dm));
+  }
+}
+
+// tasks of one matrix: [off-diagonal tiles g < h][diagonal tile copies][V tiles (row block, column pair)]
+template <int M2>
+__device__ __forceinline__ void jacobi_fused_u(const JacobiFusedArgs& p, int m, int task, float* jsm) {
+  constexpr int B = M2 / 2, PITCH = M2 + 1, NW = M2 / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = p.C, nblk = C / B, npair = nblk / 2;
+  const int n_off = npair * (npair - 1) / 2;
+  const size_t cc = (size_t)C * C;
+  const int e4 = tid * 4, lr = e4 / M2, lc = e4 % M2;     // this thread's float4 of a staged tile
+  if (task >= n_off && task < n_off + npair) {            // diagonal tile g: the image D(step_u) left behind
+    const int g = task - n_off;
+    int gi, gj;
+    block_pair(g, p.step_u, nblk, gi, gj);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p.Sr + ((size_t)m * npair + g) * (M2 * M2) + e4);
+    *reinterpret_cast<f32x4*>(p.Pw + m * cc + (size_t)pair_index<B>(lr, gi, gj) * C + pair_index<B>(lc, gi, gj)) = v;
+    return;
+  }
+  const bool is_v = task >= n_off;
+  int g, h;
+  if (is_v) { const int t = task - n_off - npair; g = t / npair; h = t % npair; }       // g = M2-row block of V
+  else { int t = task; g = 0; while (t >= npair - 1 - g) { t -= npair - 1 - g; ++g; } h = g + 1 + t; }
+  int hi, hj, gi = 0, gj = 0;
+  block_pair(h, p.step_u, nblk, hi, hj);
+  if (!is_v) block_pair(g, p.step_u, nblk, gi, gj);
+  float* Xs = jsm;
+  float* Qhs = Xs + M2 * PITCH;
+  float* Qgs = Qhs + M2 * PITCH;
+  {
+    const float* X = is_v ? p.V + m * cc : p.Pr + m * cc;
+    const int gr = is_v ? g * M2 + lr : pair_index<B>(lr, gi, gj);
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(X + (size_t)gr * C + pair_index<B>(lc, hi, hj));
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + h) * (M2 * M2) + e4);
+    f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+    if (!is_v) gv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + g) * (M2 * M2) + e4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Xs[lr * PITCH + lc + j] = xv[j];
+      Qhs[lr * PITCH + lc + j] = hv[j];
+      if (!is_v) Qgs[lr * PITCH + lc + j] = gv[j];
+    }
+  }
+  __syncthreads();
+  const int ti = wave / NW, tj = wave % NW, li = lane & 15, lq = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int kk = 0; kk < M2; kk += 4)        // T = X Qh
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[(16 * ti + li) * PITCH + kk + lq], Qhs[(kk + lq) * PITCH + 16 * tj + li], acc, 0, 0, 0);
+  if (!is_v) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[(16 * ti + 4 * lq + r) * PITCH + 16 * tj + li] = acc[r];
+    __syncthreads();
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kk = 0; kk < M2; kk += 4)      // Y = Qg^T T
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Qgs[(kk + lq) * PITCH + 16 * ti + li], Xs[(kk + lq) * PITCH + 16 * tj + li], acc, 0, 0, 0);
+    float* Pw = p.Pw + m * cc;
+    const int col = pair_index<B>(16 * tj + li, hi, hj);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Pw[(size_t)pair_index<B>(16 * ti + 4 * lq + r, gi, gj) * C + col] = acc[r];
+    // mirror tile (h, g): this lane's four rows are four consecutive columns there
+    *reinterpret_cast<f32x4*>(Pw + (size_t)col * C + pair_index<B>(16 * ti + 4 * lq, gi, gj)) = acc;
+  } else {
+    float* Vm = p.V + m * cc;
+    const int col = pair_index<B>(16 * tj + li, hi, hj);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Vm[(size_t)(g * M2 + 16 * ti + 4 * lq + r) * C + col] = acc[r];
+  }
+}
+
+// grid: [nmat * npair pair problems (if has_d)] [ntask * nmat update tasks, task-major (if has_u)]
+template <int M2>
+__global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_fused_kernel(JacobiFusedArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float jsm[];
+  constexpr int B = M2 / 2;
+  const int npair = p.C / B / 2;
+  const int n_d = p.has_d ? p.nmat * npair : 0;
+  int b = blockIdx.x;
+  if (b < n_d) {
+    const int m = b / npair, g = b % npair;
+    if (p.st[m].done) return;
+    jacobi_fused_d<M2>(p, m, g, jsm);
+  } else {
+    b -= n_d;
+    const int task = b / p.nmat, m = b % p.nmat;
+    if (p.st[m].done) return;
+    jacobi_fused_u<M2>(p, m, task, jsm);
+  }
+}
+
+// after a solve: matrices whose final state sits in the second buffer are copied back into A
+__global__ __launch_bounds__(256) void jacobi_gather_kernel(float* A, const float* P1, const JacobiState* st, int C, int cur_final) {
+  const int m = blockIdx.y;
+  const int buf = st[m].done ? st[m].pad : cur_final;
+  if (buf == 0) return;
+  const size_t cc = (size_t)C * C, n4 = cc / 4;
+  const f32x4* src = reinterpret_cast<const f32x4*>(P1 + m * cc);
+  f32x4* dst = reinterpret_cast<f32x4*>(A + m * cc);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 // mat0 = index of the group's first matrix in the 2P batch; skipped style matrices start out `done`
 __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float* V, JacobiState* st, int C, int mat0, int shared_style) {
   __shared__ float red[4];
@@ -1075,7 +1370,7 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
 // Converged = the sweep saw no rotated pair above tol_max (the classical test: the matrix was already diagonal to
 // tol_max BEFORE the sweep), or -- tol_fn > 0 -- the residual measured after the sweep is below tol_fn: the matrix
 // function built from this state with the first-order completion is then accurate to O(tol_fn^2).
-__global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int nmat, float tol_max, float tol_fn) {
+__global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int nmat, float tol_max, float tol_fn, int buf) {
   const int m = threadIdx.x;
   if (m >= nmat || st[m].done) return;
   st[m].sweeps += 1;
@@ -1088,6 +1383,7 @@ __global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int n
   const unsigned bits = st[m].offmax;                   // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
   if (bits >= 0x7f800000u || !(r2 < 3.0e38f)) st[m].done = 2;
   else if (__uint_as_float(bits) < tol_max || (tol_fn > 0.f && r2 < tol_fn * tol_fn)) st[m].done = 1;
+  if (st[m].done) st[m].pad = buf;
   st[m].last_sig = st[m].offsig;
   st[m].floor = fmaxf(st[m].floor, JACOBI_SIG_FLOOR * __uint_as_float(st[m].dmax));
   st[m].offmax = 0u;
@@ -1099,7 +1395,7 @@ __global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int n
 // of a sweep (tools/jacobi_block_order_proto.py), so a matrix that a full sweep would take 10x below the stop threshold
 // is usually below it half a sweep earlier; its remaining launches of the sweep turn into no-ops.  Touches nothing but
 // `done`, r2 / r2l and the sweep count (the half sweep counts as one).
-__global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, int nmat, float tol_fn) {
+__global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, int nmat, float tol_fn, int buf) {
   const int m = threadIdx.x;
   if (m >= nmat || st[m].done) return;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1112,6 +1408,7 @@ __global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, i
     st[m].last_sig = st[m].offsig;
     st[m].sweeps += 1;
     st[m].done = 1;
+    st[m].pad = buf;
   }
 }
 
@@ -1149,23 +1446,33 @@ static int jacobi_max_sweeps() {
 }
 
 size_t jacobi_workspace_bytes(int C, int nmat) {
-  // Q tiles: (C/M2) * M2*M2 <= C*64; state words; residual partials
-  return (size_t)nmat * C * 64 * sizeof(float) + 512 + (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_CHUNKS * 4 * sizeof(float));
+  // Q tiles: (C/M2) * M2*M2 <= C*64 per matrix -- two generations of them and of the rotated pair problems (look-ahead
+  // launches), the second matrix buffer, state words, residual partials
+  return (size_t)nmat * C * 64 * sizeof(float) * 4 + (size_t)nmat * C * C * sizeof(float) + 1024 +
+         (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_CHUNKS * 4 * sizeof(float));
 }
 
 // One group = a set of matrices on its own stream (the two halves of a batch run as two groups so
 // that one half's latency-bound pair problems hide under the other half's chip-wide tile update).
 struct JacobiGroup {
   float* A; float* V; int nmat; float* Qbuf; JacobiState* st; float* resid; hipStream_t stream; int* sweeps_out;
+  float* Qb[2]; float* Sb[2]; float* P[2];   // look-ahead path: rotations / rotated pair problems of two consecutive steps; P[0] = A
+  int cur, par;                              // buffer holding the matrices; generation of the last pair problems launched
   int mat0, shared_style;      // position in a WCT batch (skip_style_mat); 0, 0 for a plain batch
   float tol_fn;                // > 0: also stop on the measured residual (callers that complete f(A) to first order)
   int* fail;                   // device view of this group's slot [2] of the caller's status words, or null
 };
 
 // per host thread (= per ctx user): pinned copies of the groups' convergence flags and one event per group
+// (events belong to the device that was current when they were created: one set per device, so that a thread driving
+//  contexts on several GPUs never records an event of GPU 0 on a stream of GPU 1 -- ADVICE r2)
 struct JacobiHost { JacobiState* flags; hipEvent_t ev[4]; };
 static JacobiHost* jacobi_host() {
-  static thread_local JacobiHost h = {nullptr, {nullptr, nullptr, nullptr, nullptr}};
+  constexpr int MAXDEV = 16;
+  static thread_local JacobiHost hs[MAXDEV] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+  JacobiHost& h = hs[dev];
   if (!h.flags) {
     if (hipHostMalloc((void**)&h.flags, 4 * 64 * sizeof(JacobiState)) != hipSuccess) { h.flags = nullptr; return nullptr; }
     for (int g = 0; g < 4; ++g)
@@ -1240,12 +1547,12 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
       for (int g = 0; g < ngrp; ++g)
         if (grp[g].tol_fn > 0.f) {
           hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C);
-          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn);
+          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, 0);
         }
     jacobi_enqueue_steps<M2>(grp, ngrp, C, half, nblk - 1);
     for (int g = 0; g < ngrp; ++g) {
       hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C);
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn);
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, 0);
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
       for (int g = 0; g < ngrp; ++g) {
@@ -1262,12 +1569,110 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   return WCT_OK;
 }
 
+// ---- look-ahead orchestration -------------------------------------------------------------------------------------
+template <int M2>
+static void jacobi_fused_launch(JacobiGroup& G, int C, bool has_d, int step_d, bool has_u, int step_u, bool first) {
+  constexpr int B = M2 / 2, NT = B * B;
+  const int npair = C / B / 2;
+  const int ntask = npair * (npair - 1) / 2 + npair + npair * npair;
+  JacobiFusedArgs a;
+  a.Pr = G.P[G.cur]; a.Pw = G.P[G.cur ^ 1]; a.V = G.V;
+  a.Qr = G.Qb[G.par]; a.Sr = G.Sb[G.par]; a.Qw = G.Qb[G.par ^ 1]; a.Sw = G.Sb[G.par ^ 1];
+  a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_d = step_d; a.step_u = step_u;
+  a.has_d = has_d; a.has_u = has_u; a.first = first;
+  const unsigned grid = (has_d ? G.nmat * npair : 0) + (has_u ? G.nmat * ntask : 0);
+  hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+  if (has_d) G.par ^= 1;
+  if (has_u) G.cur ^= 1;
+}
+
+// steps [step_begin, step_end) of one sweep as look-ahead launches: D(begin) | {D(s), U(s-1)} ... | U(end-1); afterwards
+// the matrices are complete in P[cur].  Launches of the groups are interleaved.
+template <int M2>
+static void jacobi_enqueue_segment(JacobiGroup* grp, int ngrp, int C, int step_begin, int step_end) {
+  for (int step = step_begin; step <= step_end; ++step)
+    for (int g = 0; g < ngrp; ++g)
+      jacobi_fused_launch<M2>(grp[g], C, step < step_end, step, step > step_begin, step - 1, step == step_begin);
+}
+
+template <int M2>
+static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
+  constexpr int B = M2 / 2;
+  const int nblk = C / B;
+  const int half = -1 + nblk / 2;                 // steps [-1, half) | [half, nblk - 1)
+  const int max_sweeps = jacobi_max_sweeps();
+  static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
+  static const int mid_env = getenv("WCT_JACOBI_MID") ? atoi(getenv("WCT_JACOBI_MID")) : 3;
+  const int mid_from = nblk >= 8 ? mid_env : -1;
+  JacobiHost* host = jacobi_host();
+  for (int g = 0; g < ngrp; ++g) {
+    grp[g].cur = 0; grp[g].par = 0;
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].V, grp[g].st, C,
+                       grp[g].mat0, grp[g].shared_style);
+  }
+  bool pending = false;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    bool mid = false;
+    if (mid_from >= 0 && sweep >= mid_from)
+      for (int g = 0; g < ngrp; ++g) mid = mid || grp[g].tol_fn > 0.f;
+    if (mid) jacobi_enqueue_segment<M2>(grp, ngrp, C, -1, half);
+    else {
+      // the whole sweep is one segment; the flags of the previous sweep are looked at after its first half is enqueued
+      for (int step = -1; step < half; ++step)
+        for (int g = 0; g < ngrp; ++g)
+          jacobi_fused_launch<M2>(grp[g], C, true, step, step > -1, step - 1, step == -1);
+    }
+    if (pending) {
+      bool all = true;
+      for (int g = 0; g < ngrp; ++g) {
+        HIP_TRY(hipEventSynchronize(host->ev[g]));
+        for (int m = 0; m < grp[g].nmat; ++m) all = all && host->flags[g * 64 + m].done != 0;
+      }
+      pending = false;
+      if (all) break;          // every matrix was done before this sweep began: its launches were no-ops
+    }
+    if (mid) {
+      for (int g = 0; g < ngrp; ++g)
+        if (grp[g].tol_fn > 0.f) {
+          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C);
+          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, grp[g].cur);
+        }
+      jacobi_enqueue_segment<M2>(grp, ngrp, C, half, nblk - 1);
+    } else {
+      for (int step = half; step <= nblk - 1; ++step)
+        for (int g = 0; g < ngrp; ++g)
+          jacobi_fused_launch<M2>(grp[g], C, step < nblk - 1, step, true, step - 1, false);
+    }
+    for (int g = 0; g < ngrp; ++g) {
+      hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C);
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].cur);
+    }
+    if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
+      for (int g = 0; g < ngrp; ++g) {
+        HIP_TRY(hipMemcpyAsync(host->flags + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, grp[g].stream));
+        HIP_TRY(hipEventRecord(host->ev[g], grp[g].stream));
+      }
+      pending = true;
+    }
+  }
+  for (int g = 0; g < ngrp; ++g) {
+    hipLaunchKernelGGL(jacobi_gather_kernel, dim3(32, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].P[1], grp[g].st, C, grp[g].cur);
+    if (grp[g].sweeps_out || grp[g].fail)
+      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].fail, getenv("WCT_JACOBI_DEBUG") != nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+
 static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
                              int* sweeps_out, int* fail, hipStream_t s) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
   ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
-  const size_t qbytes = (size_t)nmat * C * 64 * sizeof(float);
+  const size_t qfloats = (size_t)nmat * C * 64;
+  const size_t qbytes = 4 * qfloats * sizeof(float) + (size_t)nmat * C * C * sizeof(float);
   G->A = A; G->V = V; G->nmat = nmat; G->Qbuf = reinterpret_cast<float*>(workspace);
+  G->Qb[0] = G->Qbuf; G->Qb[1] = G->Qbuf + qfloats; G->Sb[0] = G->Qbuf + 2 * qfloats; G->Sb[1] = G->Qbuf + 3 * qfloats;
+  G->P[0] = A; G->P[1] = G->Qbuf + 4 * qfloats; G->cur = 0; G->par = 0;
   G->st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
   G->resid = reinterpret_cast<float*>(reinterpret_cast<char*>(G->st) + (((size_t)nmat * sizeof(JacobiState) + 255) / 256) * 256);
   G->tol_fn = 0.f;
@@ -1281,8 +1686,11 @@ static int jacobi_dispatch(JacobiGroup* grp, int ngrp, int C) {
   static const int force32 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 32 : 0;
   static const int force64 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 64 : 0;
   // measured (16 matrices): 64-wide pairs win from C = 256 up (half the tile traffic), 32-wide below
-  if (!force32 && C % 64 == 0 && (C >= 256 || force64)) return jacobi_run_groups<64>(grp, ngrp, C);
-  return jacobi_run_groups<32>(grp, ngrp, C);
+  // look-ahead launches (default) or the round-2 two-launch steps (WCT_JACOBI_FUSED=0, an A-B switch)
+  static const int fused = getenv("WCT_JACOBI_FUSED") ? atoi(getenv("WCT_JACOBI_FUSED")) : 1;
+  const bool m64 = !force32 && C % 64 == 0 && (C >= 256 || force64);
+  if (fused && jacobi_pw_mode()) return m64 ? jacobi_run_groups_fused<64>(grp, ngrp, C) : jacobi_run_groups_fused<32>(grp, ngrp, C);
+  return m64 ? jacobi_run_groups<64>(grp, ngrp, C) : jacobi_run_groups<32>(grp, ngrp, C);
 }
 
 int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
