@@ -11,8 +11,11 @@
 //                     blend and re-centring folded into M and b)
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <algorithm>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 // ---------------------------------------------------------------------------
 // K3: per-channel sums over the pixel axis
@@ -484,6 +487,8 @@ struct JacobiState {
   float r2;              // strict residual measure of the last completed sweep (jacobi_resid_kernel), -1 before the first
   float r2l;             // the lenient one (what the final status is judged by)
   int pad;               // look-ahead path: the buffer (0: A, 1: the second one) that held the matrix when it was declared done
+  int seg_stop;          // number of launch segments whose rotations belong to this matrix (INT_MAX while it is still rotating)
+  int pad2;
 };
 constexpr int JACOBI_RESID_CHUNKS = 16;
 constexpr float JACOBI_SIG_FLOOR = 1e-4f;
@@ -1003,6 +1008,14 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
 // per wave.  The chain of a solve becomes D -> D -> D ...; the tile updates run beside it.
 // Data routing checked against the plain sequence in tools/jacobi_lookahead_proto.py.
 // ---------------------------------------------------------------------------
+// Phase timing build (-DJACOBI_TS, tools/r03_jacobi_ts.sh): lane 0 of every pair-problem block stamps s_memtime at its
+// phase boundaries; the launcher prints per-launch means.  Compiled out of the product.
+#ifdef JACOBI_TS
+__device__ unsigned long long jac_ts[8192 * 10];
+#define JTS(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { jac_ts[blockIdx.x * 10 + (slot)] = __builtin_amdgcn_s_memtime(); if ((slot) == 0) jac_ts[blockIdx.x * 10 + 8] = wall_clock64(); if ((slot) == 7) jac_ts[blockIdx.x * 10 + 9] = wall_clock64(); } } while (0)
+#else
+#define JTS(slot) do {} while (0)
+#endif
 struct JacobiFusedArgs {
   const float* Pr;      // [nmat][C][C] state the U part reads and the D part takes its look-ahead block from
   float* Pw;            // [nmat][C][C] state the U part writes
@@ -1014,7 +1027,19 @@ struct JacobiFusedArgs {
   int step_d, step_u;   // outer step of the pair problems / of the tile update (= the step before step_d)
   int has_d, has_u;
   int first;            // the D part loads its pair problems straight from Pr (nothing is pending on it)
+  int with_v;           // the U part also updates V (otherwise jacobi_vstrip_kernel applies the segment's rotations later)
+  int dbg;              // timing experiments (WCT_JACOBI_DBG): 1 U blocks exit at once, 2 D blocks exit at once, 4 no rotation sets
 };
+
+// Rotation matrices are stored in FRAGMENT order (the A operand of v_mfma_f32_16x16x4_f32 for V Q, see
+// jacobi_vstrip_kernel): float4 f = (mt * (M2/16) + t) * 64 + lane holds Q[16 t + 4 (lane >> 4) + r][16 mt + (lane & 15)],
+// r = 0..3.  Every consumer stages whole tiles, so the order costs the others nothing.
+template <int M2>
+__device__ __forceinline__ void qfrag_rc(int f, int& row, int& col) {
+  constexpr int NTL = M2 / 16;
+  const int l = f & 63, t = (f >> 6) % NTL, mt = (f >> 6) / NTL;
+  row = 16 * t + 4 * (l >> 4); col = 16 * mt + (l & 15);
+}
 
 // inverse of block_pair: pair index and half (0: first block, 1: second) of block b at outer step `step`
 __device__ __forceinline__ void block_locate(int b, int step, int nblk, int& g, int& half) {
@@ -1053,6 +1078,7 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
   int bi, bj;
   block_pair(g, p.step_d, nblk, bi, bj);
   const float floor_m = p.st[m].floor;
+  JTS(1);
   float my_off = 0.f, my_sig = 0.f, my_dm = 0.f;
   bool finite = true;
   float* Qo = p.Qw + ((size_t)m * npair + g) * (M2 * M2);
@@ -1102,16 +1128,21 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
       {
         const int e = tid * 4, r = e / M2, c = e % M2;
         const f32x4 xv = *reinterpret_cast<const f32x4*>(Pm + (size_t)pair_index<B>(r, b1i, b1j) * C + pair_index<B>(c, b2i, b2j));
-        // Q columns: M2 x B floats per side = NT / 2 float4; first half of the block fetches Q_g1, second half Q_g2
-        const int t2 = tid < NT / 2 ? tid : tid - NT / 2;
-        const int qe = t2 * 4, qr = qe / B, qc = qe % B;
-        const float* Qsrc = p.Qr + ((size_t)m * npair + (tid < NT / 2 ? g1 : g2)) * (M2 * M2) + qr * M2 + (tid < NT / 2 ? h1 : h2) * B + qc;
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(Qsrc);
-        float* Qdst = (tid < NT / 2 ? Q1s : Q2s) + qr * (B + 1) + qc;
+        // Q columns: M2 x B floats per side = NT / 2 float4 (the fragments mt of that half); first half of the block
+        // fetches Q_g1, second half Q_g2
+        const bool one = tid < NT / 2;
+        const int t2 = one ? tid : tid - NT / 2;
+        const int f = (one ? h1 : h2) * (NT / 2) + t2;
+        int qr, qc;
+        qfrag_rc<M2>(f, qr, qc);
+        qc -= (one ? h1 : h2) * B;
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + (one ? g1 : g2)) * (M2 * M2) + (size_t)f * 4);
+        float* Qdst = (one ? Q1s : Q2s) + qr * (B + 1) + qc;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { Xs[r * (M2 + 1) + c + j] = xv[j]; Qdst[j] = qv[j]; }
+        for (int j = 0; j < 4; ++j) { Xs[r * (M2 + 1) + c + j] = xv[j]; Qdst[j * (B + 1)] = qv[j]; }
       }
       __syncthreads();
+      JTS(2);
       const int li = lane & 15, lq = lane >> 4;
       if (wave < (B / 16) * NW) {                   // W = Q_g1[:, h1]^T X   (B x M2)
         const int tr = wave / NW, tj = wave % NW;
@@ -1130,6 +1161,7 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
           crit = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * tr + li) * (M2 + 1) + kk + lq], Q2s[(kk + lq) * (B + 1) + 16 * tc + li], crit, 0, 0, 0);
       }
       __syncthreads();                              // the staging area becomes the image
+      JTS(3);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1156,17 +1188,29 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
       if (e / M2 == e % M2) my_dm = fmaxf(my_dm, fabsf(v));
     }
   }
+  JTS(4);
   if (p.step_d >= 0) {
-    jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig);
-    for (int e = tid; e < M2 * M2; e += NT) { const f32x2 v = SQ[e]; So[e] = v[0]; Qo[e] = v[1]; }
+    if (!(p.dbg & 4)) jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig);
+    JTS(5);
+    for (int e = tid; e < M2 * M2; e += NT) So[e] = SQ[e][0];
+    int qr, qc;
+    qfrag_rc<M2>(tid, qr, qc);                      // NT float4 = one tile, fragment order
+    f32x4 q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = SQ[(qr + j) * M2 + qc][1];
+    *reinterpret_cast<f32x4*>(Qo + (size_t)tid * 4) = q;
   } else {
     constexpr int PITCH = M2 + 1;
     float* DO = jsm + 4 * M2 * PITCH;
     const int cur = jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, floor_m, my_off, my_sig);
-    for (int e = tid; e < M2 * M2; e += NT) {
-      const f32x2 v = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)];
-      So[e] = v[0]; Qo[e] = v[1];
-    }
+    JTS(5);
+    for (int e = tid; e < M2 * M2; e += NT) So[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][0];
+    int qr, qc;
+    qfrag_rc<M2>(tid, qr, qc);
+    f32x4 q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = SQ[cur * M2 * PITCH + (qr + j) * PITCH + qc][1];
+    *reinterpret_cast<f32x4*>(Qo + (size_t)tid * 4) = q;
   }
   if (!finite) my_off = __builtin_inff();
   for (int o = 32; o > 0; o >>= 1) {
@@ -1179,6 +1223,11 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
     if (my_sig > 0.f) atomicMax(&p.st[m].offsig, __float_as_uint(my_sig));
     if (my_dm > 0.f && my_dm < 3.0e38f) atomicMax(&p.st[m].dmax, __float_as_uint(my_dm));
   }
+  JTS(6);
+#ifdef JACOBI_TS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  JTS(7);
+#endif
 }
 
 // tasks of one matrix: [off-diagonal tiles g < h][diagonal tile copies][V tiles (row block, column pair)]
@@ -1198,7 +1247,7 @@ __device__ __forceinline__ void jacobi_fused_u(const JacobiFusedArgs& p, int m, 
     *reinterpret_cast<f32x4*>(p.Pw + m * cc + (size_t)pair_index<B>(lr, gi, gj) * C + pair_index<B>(lc, gi, gj)) = v;
     return;
   }
-  const bool is_v = task >= n_off;
+  const bool is_v = task >= n_off;               // (V tasks exist only in launches with_v)
   int g, h;
   if (is_v) { const int t = task - n_off - npair; g = t / npair; h = t % npair; }       // g = M2-row block of V
   else { int t = task; g = 0; while (t >= npair - 1 - g) { t -= npair - 1 - g; ++g; } h = g + 1 + t; }
@@ -1215,19 +1264,33 @@ __device__ __forceinline__ void jacobi_fused_u(const JacobiFusedArgs& p, int m, 
     const f32x4 hv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + h) * (M2 * M2) + e4);
     f32x4 gv = {0.f, 0.f, 0.f, 0.f};
     if (!is_v) gv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + g) * (M2 * M2) + e4);
+    int qr, qc;
+    qfrag_rc<M2>(tid, qr, qc);                      // the rotations arrive in fragment order
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       Xs[lr * PITCH + lc + j] = xv[j];
-      Qhs[lr * PITCH + lc + j] = hv[j];
-      if (!is_v) Qgs[lr * PITCH + lc + j] = gv[j];
+      Qhs[(qr + j) * PITCH + qc] = hv[j];
+      if (!is_v) Qgs[(qr + j) * PITCH + qc] = gv[j];
     }
   }
   __syncthreads();
   const int ti = wave / NW, tj = wave % NW, li = lane & 15, lq = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (is_v) {
+    // V Qh with the k-slots of jacobi_vstrip_kernel (MFMA (t, r) covers k = 16 t + 4 q + r, q = 0..3): an MFMA is a
+    // k-ordered fma chain per output element, so V comes out bit-identical whichever kernel updates it
+#pragma unroll
+    for (int t = 0; t < NW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * t + 4 * lq + r;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[(16 * ti + li) * PITCH + k], Qhs[k * PITCH + 16 * tj + li], acc, 0, 0, 0);
+      }
+  } else {
 #pragma unroll 4
-  for (int kk = 0; kk < M2; kk += 4)        // T = X Qh
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[(16 * ti + li) * PITCH + kk + lq], Qhs[(kk + lq) * PITCH + 16 * tj + li], acc, 0, 0, 0);
+    for (int kk = 0; kk < M2; kk += 4)      // T = X Qh
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[(16 * ti + li) * PITCH + kk + lq], Qhs[(kk + lq) * PITCH + 16 * tj + li], acc, 0, 0, 0);
+  }
   if (!is_v) {
     __syncthreads();
 #pragma unroll
@@ -1261,13 +1324,133 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_
   int b = blockIdx.x;
   if (b < n_d) {
     const int m = b / npair, g = b % npair;
-    if (p.st[m].done) return;
+    JTS(0);
+    if (p.st[m].done || (p.dbg & 2)) return;
     jacobi_fused_d<M2>(p, m, g, jsm);
   } else {
     b -= n_d;
     const int task = b / p.nmat, m = b % p.nmat;
-    if (p.st[m].done) return;
+    if (p.st[m].done || (p.dbg & 1)) return;
     jacobi_fused_u<M2>(p, m, task, jsm);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// V <- V Q for all the rotations of one launch segment, with V resident in REGISTERS (round 3).
+// Updating V inside the tile update streams the whole of V through the chip at every outer step (64 % of the update's
+// traffic: 4 MB per 512-channel matrix and step), although nothing in the solver reads V.  Here a wave owns 16 rows of V
+// -- C/16 tiles of 16x16 held as MFMA accumulators, C/4 registers per lane -- and applies the rotation matrices of all
+// the steps of a segment (the Q log the pair problems wrote) without V leaving the registers:
+//   (V Q_h)^T = Q_h^T V^T is computed tile by tile with v_mfma_f32_16x16x4_f32; a 16x16 tile of V^T in the C/D layout
+//   (lane (n, q), register r  <->  V[row n][tile column 4 q + r]) is ALREADY the B operand of the k-step that covers the
+//   columns {4 q + r : q = 0..3}, so the old tiles feed the MFMAs straight from the accumulator registers, the results
+//   arrive in the same layout, and the only operand that is loaded is Q (fragment order: one 16-byte LDS read per
+//   four MFMAs; the tile of a pair is staged once per block, double-buffered).
+// Register indices must be static: the strip is kept in POSITION order of the round-robin pairing (pair g = positions g
+// and NBLK-1-g; the intra step pairs positions 2g, 2g+1, natural order = the order of step 0); advancing one outer step
+// moves position pos+1 to pos (pos >= 1) and position 1 to NBLK-1 -- a static register rotation.
+// V traffic: one read and one write per SEGMENT instead of per step.  Runs on a side stream behind the segment, beside
+// the next segment's pair problems (MFMA pipe and registers here, LDS and VALU there).
+// ---------------------------------------------------------------------------
+struct VStripArgs {
+  float* V; const float* Qlog;      // Qlog: [slot][nmat][npair][M2*M2] fragment order, slot = step - step_begin
+  const JacobiState* st;
+  int C, nmat, step_begin, step_end, seg;
+};
+
+template <int M2, int NBLK, int W>
+__global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
+  constexpr int B = M2 / 2, TB = B / 16, NTL = M2 / 16, NPAIR = NBLK / 2, FR = M2 * M2, C = NBLK * B;
+  constexpr int NLD = FR / 4 / (W * 64) > 0 ? FR / 4 / (W * 64) : 1;        // float4 per thread and tile
+  __shared__ __attribute__((aligned(16))) float qs[2][FR];
+  const int m = blockIdx.y;
+  if (p.st[m].seg_stop <= p.seg) return;        // no rotations of this segment belong to the matrix (done before it began)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  const int row0 = (blockIdx.x * W + wave) * 16;
+  float* Vm = p.V + (size_t)m * C * C + (size_t)(row0 + li) * C + 4 * lq;
+  f32x4 v[NBLK * TB];
+  auto block_at = [&](int pos, int step) { return step < 0 ? pos : rr_idx(pos, step, NBLK); };
+#pragma unroll
+  for (int pos = 0; pos < NBLK; ++pos) {
+    const int blk = block_at(pos, p.step_begin);
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) v[pos * TB + tb] = *reinterpret_cast<const f32x4*>(Vm + blk * B + tb * 16);
+  }
+  const size_t slot_stride = (size_t)p.nmat * NPAIR * FR;
+  const float* qbase = p.Qlog + (size_t)m * NPAIR * FR;
+  // tile q of the segment: step = step_begin + q / NPAIR, pair = q % NPAIR
+  const int ntile = (p.step_end - p.step_begin) * NPAIR;
+  f32x4 pre[NLD];
+  auto fetch = [&](int q) {
+    const float* src = qbase + (size_t)(q / NPAIR) * slot_stride + (size_t)(q % NPAIR) * FR;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + i * W * 64;
+      if (FR / 4 >= W * 64 || f < FR / 4) pre[i] = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
+    }
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int f = tid + i * W * 64;
+      if (FR / 4 >= W * 64 || f < FR / 4) *reinterpret_cast<f32x4*>(&qs[buf][f * 4]) = pre[i];
+    }
+  };
+  fetch(0);
+  park(0);
+  __syncthreads();
+  int q = 0;
+  // one pair: tiles x[0..2TB) = positions pa, pb; out[mt] = sum_t sum_r mfma(Qf[mt][t][r], x[t][r]).  pa / pb are
+  // compile-time constants once the loops over g below are unrolled (the strip must stay in registers)
+#define VSTRIP_PAIR(pa, pb)                                                                                          \
+  {                                                                                                                  \
+    if (q + 1 < ntile) fetch(q + 1);                                                                                 \
+    const float* qb = qs[q & 1];                                                                                     \
+    f32x4 out[2 * TB];                                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};                      \
+    _Pragma("unroll") for (int t = 0; t < 2 * TB; ++t) {                                                             \
+      const f32x4 x = t < TB ? v[(pa) * TB + t] : v[(pb) * TB + t - TB];                                             \
+      f32x4 a[2 * TB];                                                                                               \
+      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                          \
+        a[mt] = *reinterpret_cast<const f32x4*>(qb + ((mt * NTL + t) * 64 + lane) * 4);                              \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                        \
+          out[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][r], x[r], out[mt], 0, 0, 0);                          \
+    }                                                                                                                \
+    _Pragma("unroll") for (int t = 0; t < TB; ++t) { v[(pa) * TB + t] = out[t]; v[(pb) * TB + t] = out[TB + t]; }    \
+    if (q + 1 < ntile) park((q + 1) & 1);                                                                            \
+    __syncthreads();                                                                                                 \
+    ++q;                                                                                                             \
+  }
+#pragma unroll 1
+  for (int step = p.step_begin; step < p.step_end; ++step) {
+    if (step < 0) {
+#pragma unroll
+      for (int g = 0; g < NPAIR; ++g) VSTRIP_PAIR(2 * g, 2 * g + 1)          // natural order
+    } else {
+#pragma unroll
+      for (int g = 0; g < NPAIR; ++g) VSTRIP_PAIR(g, NBLK - 1 - g)
+      if (step + 1 < p.step_end && NBLK > 2) {        // positions of the next step: pos <- pos + 1, NBLK - 1 <- 1
+        f32x4 keep[TB];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) keep[tb] = v[1 * TB + tb];
+#pragma unroll
+        for (int pos = 1; pos < NBLK - 1; ++pos)
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) v[pos * TB + tb] = v[(pos + 1) * TB + tb];
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb) v[(NBLK - 1) * TB + tb] = keep[tb];
+      }
+    }
+  }
+#undef VSTRIP_PAIR
+  const int last = p.step_end - 1;
+#pragma unroll
+  for (int pos = 0; pos < NBLK; ++pos) {
+    const int blk = block_at(pos, last);
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb) *reinterpret_cast<f32x4*>(Vm + blk * B + tb * 16) = v[pos * TB + tb];
   }
 }
 
@@ -1302,6 +1485,7 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
       JacobiState z;
       z.offmax = 0u; z.done = skip ? 1 : 0; z.sweeps = 0; z.offsig = 0u;
       z.floor = JACOBI_SIG_FLOOR * fminf(mx, 3.0e38f); z.last_sig = 0u; z.dmax = 0u; z.r2 = -1.f; z.r2l = -1.f; z.pad = 0;
+      z.seg_stop = skip ? 0 : 0x7fffffff; z.pad2 = 0;
       st[m] = z;
     }
   }
@@ -1370,7 +1554,7 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
 // Converged = the sweep saw no rotated pair above tol_max (the classical test: the matrix was already diagonal to
 // tol_max BEFORE the sweep), or -- tol_fn > 0 -- the residual measured after the sweep is below tol_fn: the matrix
 // function built from this state with the first-order completion is then accurate to O(tol_fn^2).
-__global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int nmat, float tol_max, float tol_fn, int buf) {
+__global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int nmat, float tol_max, float tol_fn, int buf, int segs = 0) {
   const int m = threadIdx.x;
   if (m >= nmat || st[m].done) return;
   st[m].sweeps += 1;
@@ -1383,7 +1567,7 @@ __global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int n
   const unsigned bits = st[m].offmax;                   // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
   if (bits >= 0x7f800000u || !(r2 < 3.0e38f)) st[m].done = 2;
   else if (__uint_as_float(bits) < tol_max || (tol_fn > 0.f && r2 < tol_fn * tol_fn)) st[m].done = 1;
-  if (st[m].done) st[m].pad = buf;
+  if (st[m].done) { st[m].pad = buf; st[m].seg_stop = segs; }
   st[m].last_sig = st[m].offsig;
   st[m].floor = fmaxf(st[m].floor, JACOBI_SIG_FLOOR * __uint_as_float(st[m].dmax));
   st[m].offmax = 0u;
@@ -1395,7 +1579,7 @@ __global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int n
 // of a sweep (tools/jacobi_block_order_proto.py), so a matrix that a full sweep would take 10x below the stop threshold
 // is usually below it half a sweep earlier; its remaining launches of the sweep turn into no-ops.  Touches nothing but
 // `done`, r2 / r2l and the sweep count (the half sweep counts as one).
-__global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, int nmat, float tol_fn, int buf) {
+__global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, int nmat, float tol_fn, int buf, int segs = 0) {
   const int m = threadIdx.x;
   if (m >= nmat || st[m].done) return;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1409,6 +1593,7 @@ __global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, i
     st[m].sweeps += 1;
     st[m].done = 1;
     st[m].pad = buf;
+    st[m].seg_stop = segs;
   }
 }
 
@@ -1446,9 +1631,10 @@ static int jacobi_max_sweeps() {
 }
 
 size_t jacobi_workspace_bytes(int C, int nmat) {
-  // Q tiles: (C/M2) * M2*M2 <= C*64 per matrix -- two generations of them and of the rotated pair problems (look-ahead
-  // launches), the second matrix buffer, state words, residual partials
-  return (size_t)nmat * C * 64 * sizeof(float) * 4 + (size_t)nmat * C * C * sizeof(float) + 1024 +
+  // per matrix: the rotation log of two launch segments (2 x C/B steps x C/M2 tiles x M2^2 = 4 C^2 floats for both block
+  // widths), two generations of rotated pair problems (2 x C x M2 <= 128 C), the second matrix buffer (C^2); then state
+  // words and residual partials
+  return (size_t)nmat * ((size_t)5 * C * C + (size_t)128 * C) * sizeof(float) + 1024 +
          (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_CHUNKS * 4 * sizeof(float));
 }
 
@@ -1456,8 +1642,13 @@ size_t jacobi_workspace_bytes(int C, int nmat) {
 // that one half's latency-bound pair problems hide under the other half's chip-wide tile update).
 struct JacobiGroup {
   float* A; float* V; int nmat; float* Qbuf; JacobiState* st; float* resid; hipStream_t stream; int* sweeps_out;
-  float* Qb[2]; float* Sb[2]; float* P[2];   // look-ahead path: rotations / rotated pair problems of two consecutive steps; P[0] = A
-  int cur, par;                              // buffer holding the matrices; generation of the last pair problems launched
+  float* Qlog[2]; float* Sb[2]; float* P[2]; // look-ahead path: rotation logs of two segments, rotated pair problems of two
+                                             // consecutive steps, the two matrix buffers (P[0] = A)
+  int cur, par, lg, segs;                    // buffer holding the matrices; generation of the last pair problems; log in use;
+                                             // segments completed
+  int vstrip;                                // V is updated per segment by jacobi_vstrip_kernel on the side stream `vs`
+  hipStream_t vs; hipEvent_t ev_seg, ev_v[2];// main -> side (segment enqueued), side -> main (log buffer free again)
+  bool v_busy[2];
   int mat0, shared_style;      // position in a WCT batch (skip_style_mat); 0, 0 for a plain batch
   float tol_fn;                // > 0: also stop on the measured residual (callers that complete f(A) to first order)
   int* fail;                   // device view of this group's slot [2] of the caller's status words, or null
@@ -1466,7 +1657,7 @@ struct JacobiGroup {
 // per host thread (= per ctx user): pinned copies of the groups' convergence flags and one event per group
 // (events belong to the device that was current when they were created: one set per device, so that a thread driving
 //  contexts on several GPUs never records an event of GPU 0 on a stream of GPU 1 -- ADVICE r2)
-struct JacobiHost { JacobiState* flags; hipEvent_t ev[4]; };
+struct JacobiHost { JacobiState* flags; hipEvent_t ev[4]; hipStream_t vs[4]; hipEvent_t ev_seg[4], ev_v[4][2]; };
 static JacobiHost* jacobi_host() {
   constexpr int MAXDEV = 16;
   static thread_local JacobiHost hs[MAXDEV] = {};
@@ -1475,8 +1666,15 @@ static JacobiHost* jacobi_host() {
   JacobiHost& h = hs[dev];
   if (!h.flags) {
     if (hipHostMalloc((void**)&h.flags, 4 * 64 * sizeof(JacobiState)) != hipSuccess) { h.flags = nullptr; return nullptr; }
-    for (int g = 0; g < 4; ++g)
-      if (hipEventCreateWithFlags(&h.ev[g], hipEventDisableTiming) != hipSuccess) { hipHostFree(h.flags); h.flags = nullptr; return nullptr; }
+    bool ok = true;
+    for (int g = 0; g < 4 && ok; ++g) {
+      ok = hipEventCreateWithFlags(&h.ev[g], hipEventDisableTiming) == hipSuccess &&
+           hipStreamCreateWithFlags(&h.vs[g], hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&h.ev_seg[g], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&h.ev_v[g][0], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&h.ev_v[g][1], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { (void)hipHostFree(h.flags); h.flags = nullptr; return nullptr; }
   }
   return &h;
 }
@@ -1570,29 +1768,114 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
 }
 
 // ---- look-ahead orchestration -------------------------------------------------------------------------------------
+// launch { D(step_d) writing log slot step_d - seg_begin, U(step_u) reading slot step_u - seg_begin }
 template <int M2>
-static void jacobi_fused_launch(JacobiGroup& G, int C, bool has_d, int step_d, bool has_u, int step_u, bool first) {
+static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d, int step_d, bool has_u, int step_u, bool first) {
   constexpr int B = M2 / 2, NT = B * B;
   const int npair = C / B / 2;
-  const int ntask = npair * (npair - 1) / 2 + npair + npair * npair;
+  const int ntask = npair * (npair - 1) / 2 + npair + (G.vstrip ? 0 : npair * npair);
+  const size_t slot = (size_t)G.nmat * npair * M2 * M2;
   JacobiFusedArgs a;
   a.Pr = G.P[G.cur]; a.Pw = G.P[G.cur ^ 1]; a.V = G.V;
-  a.Qr = G.Qb[G.par]; a.Sr = G.Sb[G.par]; a.Qw = G.Qb[G.par ^ 1]; a.Sw = G.Sb[G.par ^ 1];
+  a.Qr = G.Qlog[G.lg] + (size_t)(step_u - seg_begin) * slot; a.Qw = G.Qlog[G.lg] + (size_t)(step_d - seg_begin) * slot;
+  a.Sr = G.Sb[G.par]; a.Sw = G.Sb[G.par ^ 1];
   a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_d = step_d; a.step_u = step_u;
-  a.has_d = has_d; a.has_u = has_u; a.first = first;
+  a.has_d = has_d; a.has_u = has_u; a.first = first; a.with_v = !G.vstrip;
+  static const int dbg = getenv("WCT_JACOBI_DBG") ? atoi(getenv("WCT_JACOBI_DBG")) : 0;
+  a.dbg = dbg;
   const unsigned grid = (has_d ? G.nmat * npair : 0) + (has_u ? G.nmat * ntask : 0);
   hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+#ifdef JACOBI_TS
+  if (has_d && !first && step_d >= 0 && M2 == 64) {
+    static int nlaunch = 0, last_nmat = 0;
+    static double sum[8] = {0}, span = 0;
+    if (G.nmat != last_nmat) { nlaunch = 0; span = 0; for (double& v : sum) v = 0; last_nmat = G.nmat; }
+    (void)hipStreamSynchronize(G.stream);
+    static unsigned long long host[8192 * 10];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(jac_ts), sizeof(host));
+    const int nb = G.nmat * npair < 8192 ? G.nmat * npair : 8192;
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int i = 0; i < nb; ++i) {
+      const unsigned long long* t = host + i * 10;
+      for (int k = 0; k < 7; ++k) sum[k] += (double)(t[k + 1] - t[k]) / nb;
+      if (t[8] < lo) lo = t[8];
+      if (t[9] > hi) hi = t[9];
+    }
+    if (nlaunch == 0) {
+      int occ = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, jacobi_fused_kernel<M2>, NT, jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
+      printf("jacobi_ts: occupancy API says %d blocks of %d threads per CU with %zu B of LDS\n", occ, NT, jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
+    }
+    span += (double)(hi - lo);
+    if (nlaunch == 40) {
+      std::vector<unsigned long long> st0, en0;
+      for (int i = 0; i < nb; ++i) { st0.push_back(host[i * 10 + 8] - lo); en0.push_back(host[i * 10 + 9] - lo); }
+      std::sort(st0.begin(), st0.end()); std::sort(en0.begin(), en0.end());
+      printf("jacobi_ts nmat %d launch 40: block start offsets (10 ns ticks) p0 %llu p25 %llu p50 %llu p75 %llu p90 %llu p100 %llu | end offsets p0 %llu p50 %llu p100 %llu\n", G.nmat,
+             st0[0], st0[nb / 4], st0[nb / 2], st0[3 * nb / 4], st0[9 * nb / 10], st0[nb - 1], en0[0], en0[nb / 2], en0[nb - 1]);
+    }
+    if (++nlaunch % 32 == 0) {
+      printf("jacobi_ts nmat %d (%d launches): state %.0f | loads->LDS %.0f | crit %.0f | image %.0f | sets %.0f | stores issued %.0f | drained %.0f | first start -> last end %.0f wall-clock ticks (100 MHz) (others: s_memtime ticks)\n",
+             G.nmat, nlaunch, sum[0] / nlaunch, sum[1] / nlaunch, sum[2] / nlaunch, sum[3] / nlaunch, sum[4] / nlaunch, sum[5] / nlaunch, sum[6] / nlaunch, span / nlaunch);
+      fflush(stdout);
+    }
+  }
+#endif
   if (has_d) G.par ^= 1;
   if (has_u) G.cur ^= 1;
 }
 
-// steps [step_begin, step_end) of one sweep as look-ahead launches: D(begin) | {D(s), U(s-1)} ... | U(end-1); afterwards
-// the matrices are complete in P[cur].  Launches of the groups are interleaved.
+// which (block width, block count) combinations jacobi_vstrip_kernel is instantiated for
 template <int M2>
-static void jacobi_enqueue_segment(JacobiGroup* grp, int ngrp, int C, int step_begin, int step_end) {
-  for (int step = step_begin; step <= step_end; ++step)
+static bool vstrip_supported(int C) {
+  const int nblk = C / (M2 / 2);
+  return M2 == 64 ? (nblk == 8 || nblk == 16) : (nblk == 2 || nblk == 4 || nblk == 8);
+}
+template <int M2>
+static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_end, hipStream_t s) {
+  const int nblk = C / (M2 / 2);
+  VStripArgs a;
+  a.V = G.V; a.Qlog = G.Qlog[G.lg]; a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_begin = step_begin; a.step_end = step_end; a.seg = G.segs;
+#define VSTRIP_CASE(m2, nb, w) \
+  if (M2 == m2 && nblk == nb) hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), dim3(C / 16 / w, G.nmat), dim3(w * 64), 0, s, a);
+  VSTRIP_CASE(64, 16, 4) VSTRIP_CASE(64, 8, 8) VSTRIP_CASE(32, 8, 4) VSTRIP_CASE(32, 4, 4) VSTRIP_CASE(32, 2, 2)
+#undef VSTRIP_CASE
+}
+
+// before the first launch of a segment: its log buffer must not be in use by a V pass any more
+static int jacobi_segment_begin(JacobiGroup* grp, int ngrp) {
+  for (int g = 0; g < ngrp; ++g) {
+    JacobiGroup& G = grp[g];
+    if (G.vstrip && G.v_busy[G.lg]) { HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_v[G.lg], 0)); G.v_busy[G.lg] = false; }
+  }
+  return WCT_OK;
+}
+// after the last launch of a segment (steps [step_begin, step_end)): hand its log to the V pass, switch logs
+template <int M2>
+static int jacobi_segment_end(JacobiGroup* grp, int ngrp, int C, int step_begin, int step_end) {
+  for (int g = 0; g < ngrp; ++g) {
+    JacobiGroup& G = grp[g];
+    if (G.vstrip) {
+      HIP_TRY(hipEventRecord(G.ev_seg, G.stream));
+      HIP_TRY(hipStreamWaitEvent(G.vs, G.ev_seg, 0));
+      vstrip_launch<M2>(G, C, step_begin, step_end, G.vs);
+      HIP_TRY(hipEventRecord(G.ev_v[G.lg], G.vs));
+      G.v_busy[G.lg] = true;
+      G.lg ^= 1;
+    }
+    G.segs += 1;
+  }
+  return WCT_OK;
+}
+
+// steps [step_begin, step_end) of one sweep as look-ahead launches: D(begin) | {D(s), U(s-1)} ... | U(end-1); afterwards
+// the matrices are complete in P[cur].  Launches of the groups are interleaved.  [lo, hi) restricts the launches that
+// are enqueued by this call to those of index lo..hi-1 (index = step of the D part; hi = step_end is the closing U).
+template <int M2>
+static void jacobi_enqueue_segment(JacobiGroup* grp, int ngrp, int C, int step_begin, int step_end, int lo, int hi) {
+  for (int step = lo; step < hi; ++step)
     for (int g = 0; g < ngrp; ++g)
-      jacobi_fused_launch<M2>(grp[g], C, step < step_end, step, step > step_begin, step - 1, step == step_begin);
+      jacobi_fused_launch<M2>(grp[g], C, step_begin, step < step_end, step, step > step_begin, step - 1, step == step_begin);
 }
 
 template <int M2>
@@ -1603,25 +1886,29 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
   const int max_sweeps = jacobi_max_sweeps();
   static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
   static const int mid_env = getenv("WCT_JACOBI_MID") ? atoi(getenv("WCT_JACOBI_MID")) : 3;
+  // V in registers, per segment (jacobi_vstrip_kernel): 0 never, 1 from WCT_JACOBI_VSTRIP_MIN matrices per group on, 2 always
+  static const int vs_env = getenv("WCT_JACOBI_VSTRIP") ? atoi(getenv("WCT_JACOBI_VSTRIP")) : 1;
+  static const int vs_min = getenv("WCT_JACOBI_VSTRIP_MIN") ? atoi(getenv("WCT_JACOBI_VSTRIP_MIN")) : 8;
   const int mid_from = nblk >= 8 ? mid_env : -1;
   JacobiHost* host = jacobi_host();
   for (int g = 0; g < ngrp; ++g) {
-    grp[g].cur = 0; grp[g].par = 0;
-    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].V, grp[g].st, C,
-                       grp[g].mat0, grp[g].shared_style);
+    JacobiGroup& G = grp[g];
+    G.cur = 0; G.par = 0; G.lg = 0; G.segs = 0; G.v_busy[0] = G.v_busy[1] = false;
+    G.vstrip = host && g < 4 && vstrip_supported<M2>(C) && (vs_env == 2 || (vs_env == 1 && G.nmat >= vs_min && C >= 256));
+    if (G.vstrip) { G.vs = host->vs[g]; G.ev_seg = host->ev_seg[g]; G.ev_v[0] = host->ev_v[g][0]; G.ev_v[1] = host->ev_v[g][1]; }
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, G.nmat), dim3(256), 0, G.stream, G.A, G.V, G.st, C, G.mat0, G.shared_style);
   }
   bool pending = false;
+  int rc;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     bool mid = false;
     if (mid_from >= 0 && sweep >= mid_from)
       for (int g = 0; g < ngrp; ++g) mid = mid || grp[g].tol_fn > 0.f;
-    if (mid) jacobi_enqueue_segment<M2>(grp, ngrp, C, -1, half);
-    else {
-      // the whole sweep is one segment; the flags of the previous sweep are looked at after its first half is enqueued
-      for (int step = -1; step < half; ++step)
-        for (int g = 0; g < ngrp; ++g)
-          jacobi_fused_launch<M2>(grp[g], C, true, step, step > -1, step - 1, step == -1);
-    }
+    // segments of this sweep: [-1, half) + [half, nblk - 1) around a residual test, or the whole sweep in one
+    const int end1 = mid ? half : nblk - 1;
+    if ((rc = jacobi_segment_begin(grp, ngrp))) return rc;
+    // the flags of the previous sweep are looked at once half a sweep of launches is enqueued (the GPU never idles)
+    jacobi_enqueue_segment<M2>(grp, ngrp, C, -1, end1, -1, half);
     if (pending) {
       bool all = true;
       for (int g = 0; g < ngrp; ++g) {
@@ -1631,21 +1918,21 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
       pending = false;
       if (all) break;          // every matrix was done before this sweep began: its launches were no-ops
     }
+    jacobi_enqueue_segment<M2>(grp, ngrp, C, -1, end1, half, end1 + 1);
+    if ((rc = jacobi_segment_end<M2>(grp, ngrp, C, -1, end1))) return rc;
     if (mid) {
       for (int g = 0; g < ngrp; ++g)
         if (grp[g].tol_fn > 0.f) {
           hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C);
-          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, grp[g].cur);
+          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, grp[g].cur, grp[g].segs);
         }
-      jacobi_enqueue_segment<M2>(grp, ngrp, C, half, nblk - 1);
-    } else {
-      for (int step = half; step <= nblk - 1; ++step)
-        for (int g = 0; g < ngrp; ++g)
-          jacobi_fused_launch<M2>(grp[g], C, step < nblk - 1, step, true, step - 1, false);
+      if ((rc = jacobi_segment_begin(grp, ngrp))) return rc;
+      jacobi_enqueue_segment<M2>(grp, ngrp, C, half, nblk - 1, half, nblk);
+      if ((rc = jacobi_segment_end<M2>(grp, ngrp, C, half, nblk - 1))) return rc;
     }
     for (int g = 0; g < ngrp; ++g) {
       hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C);
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].cur);
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs);
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
       for (int g = 0; g < ngrp; ++g) {
@@ -1656,9 +1943,12 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     }
   }
   for (int g = 0; g < ngrp; ++g) {
-    hipLaunchKernelGGL(jacobi_gather_kernel, dim3(32, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].P[1], grp[g].st, C, grp[g].cur);
-    if (grp[g].sweeps_out || grp[g].fail)
-      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].fail, getenv("WCT_JACOBI_DEBUG") != nullptr);
+    JacobiGroup& G = grp[g];
+    for (int l = 0; l < 2; ++l)            // the V passes still in flight belong to this solve
+      if (G.vstrip && G.v_busy[l]) { HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_v[l], 0)); G.v_busy[l] = false; }
+    hipLaunchKernelGGL(jacobi_gather_kernel, dim3(32, G.nmat), dim3(256), 0, G.stream, G.A, G.P[1], G.st, C, G.cur);
+    if (G.sweeps_out || G.fail)
+      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, G.stream, G.st, G.sweeps_out, G.nmat, conv_tol, G.tol_fn, G.fail, getenv("WCT_JACOBI_DEBUG") != nullptr);
   }
   HIP_TRY(hipGetLastError());
   return WCT_OK;
@@ -1668,11 +1958,13 @@ static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat
                              int* sweeps_out, int* fail, hipStream_t s) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
   ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
-  const size_t qfloats = (size_t)nmat * C * 64;
-  const size_t qbytes = 4 * qfloats * sizeof(float) + (size_t)nmat * C * C * sizeof(float);
+  const size_t cc = (size_t)C * C;
+  const size_t qbytes = (size_t)nmat * (5 * cc + (size_t)128 * C) * sizeof(float);
   G->A = A; G->V = V; G->nmat = nmat; G->Qbuf = reinterpret_cast<float*>(workspace);
-  G->Qb[0] = G->Qbuf; G->Qb[1] = G->Qbuf + qfloats; G->Sb[0] = G->Qbuf + 2 * qfloats; G->Sb[1] = G->Qbuf + 3 * qfloats;
-  G->P[0] = A; G->P[1] = G->Qbuf + 4 * qfloats; G->cur = 0; G->par = 0;
+  G->Qlog[0] = G->Qbuf; G->Qlog[1] = G->Qbuf + 2 * cc * nmat;
+  G->Sb[0] = G->Qbuf + 4 * cc * nmat; G->Sb[1] = G->Sb[0] + (size_t)64 * C * nmat;
+  G->P[0] = A; G->P[1] = G->Sb[1] + (size_t)64 * C * nmat; G->cur = 0; G->par = 0; G->lg = 0; G->segs = 0;
+  G->vstrip = 0; G->vs = nullptr; G->v_busy[0] = G->v_busy[1] = false;
   G->st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
   G->resid = reinterpret_cast<float*>(reinterpret_cast<char*>(G->st) + (((size_t)nmat * sizeof(JacobiState) + 255) / 256) * 256);
   G->tol_fn = 0.f;
@@ -2106,7 +2398,10 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       // batch 32: 1 group 31.6, 2: 30.0, 3: 28.4, 4: 28.0; batch 16: 19.9 / 19.5 / - / 18.2; batch 8: 15.6 / 15.5 / 15.2 /
       // 15.6; batch 4: 13.2 / 13.5 / - / 14.1; batch 2: 11.8 / 12.1 / - / 12.9 -- many matrices: one group's pair
       // problems hide under the other groups' tile updates; few: every extra stream only adds launch traffic
-      int ngrp = P >= 12 ? 4 : (P >= 6 ? 2 : 1);
+      // round 3: with the look-ahead launches a group's pair problems already run beside its own tile update, and more
+      // groups only split the chip (Jacobi ms per step, 1 / 2 / 4 groups: batch 32: 20.6 / 21.0 / 22.5, batch 8: 9.3 / 11.9 / 10.0)
+      static const int fused_on = getenv("WCT_JACOBI_FUSED") ? atoi(getenv("WCT_JACOBI_FUSED")) : 1;
+      int ngrp = fused_on ? 1 : (P >= 12 ? 4 : (P >= 6 ? 2 : 1));
       if (ngrp > nside + 1) ngrp = nside + 1;
       static const int force_ngrp = getenv("WCT_EIG_NGRP") ? atoi(getenv("WCT_EIG_NGRP")) : 0;   // tuning switch
       if (force_ngrp >= 1 && force_ngrp <= 4 && force_ngrp <= nside + 1) ngrp = force_ngrp;
