@@ -15,7 +15,14 @@ in -> host uint8 out: SURVEY 8d asks for both figures) and `cpu_baseline` (BASEL
 NumPy transform + torch-CPU conv stand-in on this host's cores, rank 0, N=1).
 
 Scaling modes: weak (default; --batch pairs per GPU per step) and strong (--global-batch G pairs
-per step in total: BASELINE configs[3] is --global-batch 64 on 8 GPUs = 8 pairs per GPU).
+per step in total: BASELINE configs[3] is --global-batch 64 on 8 GPUs = 8 pairs per GPU).  With --gpus N > 1 the
+headline is the weak figure and the same line carries a `strong` sub-record (64 pairs per step over the N GPUs,
+timed right after), so one driver run measures configs[3] as written.
+
+`eigensolver` in the line: ms per step, the sweeps the covariances took (mean / max per channel count), the
+fp32-MFMA rate of its tile updates against the 157.3 TFLOP/s peak, and `hard_spectrum`: the transform on graded
+512-channel covariances (eigenvalues over 6 decades; N = 4096 and N = 256 < C) -- `--spectrum graded` prints only
+that leg.
 """
 import argparse
 import json
@@ -63,11 +70,54 @@ def conv_flops_per_frame(size):
     return enc(5) + sum(enc(RELU_LEVEL[r]) for r in LEVELS) + sum(dec(r) for r in LEVELS)
 
 
+F32_MFMA_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_* at the fp32 vector rate
+
+
+def jacobi_flops_per_sweep(c):
+    """fp32-MFMA FLOPs of one sweep of the block Jacobi on one C x C matrix: per outer step the two-sided update of the
+    off-diagonal tiles (two M2^3 products each, mirror tiles are copies) and V <- V Q (C rows x the pairs' M2 x M2
+    rotations); C/B outer steps per sweep.  Block pairs of 64 indices from C = 256 up, 32 below (csrc/wct.hip)."""
+    m2 = 64 if (c >= 256 and c % 64 == 0) else 32
+    nblk = c // (m2 // 2)
+    npair = nblk // 2
+    n_off = npair * (npair - 1) // 2
+    return nblk * (n_off * 2 * 2.0 * m2 ** 3 + 2.0 * c * c * m2)
+
+
+def graded_features(seed, n, c, decades):
+    """post-ReLU-like features whose covariance is graded: per-channel scales log-spaced over `decades`/2 (eigenvalues
+    over ~`decades`), mild channel mixing"""
+    rng = np.random.default_rng(seed)
+    mix = np.eye(c) + 0.3 * rng.standard_normal((c, c)) / np.sqrt(c)
+    d = 10.0 ** (-np.arange(c) * decades / (c - 1) / 2)
+    return np.float32(np.maximum(rng.standard_normal((n, c)) @ mix + 0.3, 0) * d * 3.0)
+
+
+def hard_spectrum_leg(ctx, c=512, decades=6.0):
+    """Sweeps and eigensolver time of wct_transform (one pair, wct_tf semantics) on graded covariances: N = 8 C
+    (full rank, eigenvalues over `decades`) and N = C / 2 (rank-deficient: the null space is rounding noise)."""
+    from wct_tf_amd import _lib
+    out = []
+    for n in (8 * c, c // 2):
+        fc, fs = graded_features(11, n, c, decades), graded_features(12, n, c, decades)
+        ctx.transform(fc, fs, 0.8, _lib.WCT_TF)
+        ctx.prof_reset(); ctx.prof_enable(True)
+        reps = 5
+        for _ in range(reps):
+            _, sweeps = ctx.transform(fc, fs, 0.8, _lib.WCT_TF, return_sweeps=True)
+        ctx.prof_enable(False)
+        ms = ctx.prof_read()['jacobi']['ms'] / reps
+        out.append({'C': c, 'N': n, 'eigenvalue_decades': decades, 'sweeps_content_style': [int(x) for x in sweeps[:2]],
+                    'eigensolver_ms': ms})
+    ctx.eig_stats()
+    return out
+
+
 def pmc_traffic(batch, size):
     """HBM bytes per conv3x3 launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
     runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read from inside this
     process, so the figure is the profile of this exact workload, not a measurement of this run; null otherwise."""
-    for tag in ('r02_final', 'r01_final'):
+    for tag in ('r03_final', 'r02_final', 'r01_final'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_conv3x3.json' % tag)
         if batch == PMC_BATCH and size == 512 and os.path.exists(path):
             return json.load(open(path))['hbm_bytes_per_launch_corrected'], 'profiles/%s_pmc_hbm.csv' % tag
@@ -86,12 +136,15 @@ def cpu_baseline(size, weights, alpha):
     c = synthetic_image(1000, size, size)
     s = synthetic_image(2000, size, size)
     path.stylize(c, s, LEVELS, alpha, 'tf')
-    times = []
+    times, t_transform = [], []
     for _ in range(5):
+        timers = {}
         t0 = time.time()
-        path.stylize(c, s, LEVELS, alpha, 'tf')
+        path.stylize(c, s, LEVELS, alpha, 'tf', timers=timers)
         times.append(time.time() - t0)
+        t_transform.append(timers['transform_s'])
     med = sorted(times)[len(times) // 2]
+    med_t = sorted(t_transform)[len(t_transform) // 2]
     try:
         from threadpoolctl import threadpool_info
         blas = max([p.get('num_threads', 0) for p in threadpool_info() if p.get('user_api') == 'blas'] or [0])
@@ -99,6 +152,9 @@ def cpu_baseline(size, weights, alpha):
         blas = 0
     return {'value': 1.0 / med, 'unit': 'frames/s', 'cores': max(torch.get_num_threads(), blas), 'kind': 'port',
             'host_cores': os.cpu_count(), 'torch_threads': torch.get_num_threads(), 'blas_threads': blas,
+            # part (i), the reference's transform in NumPy (five whiten-colour transforms per frame, LAPACK
+            # SVD), reported separately from part (ii), the torch-CPU stand-in for the CPU-TF conv stack
+            'transform_s': med_t, 'conv_standin_s': med - med_t,
             'sample': '1 warm-up + median of 5 frames %dx%d, 5-level, alpha %.1f: NumPy transform (restatement of the reference\'s '
                       'wct_tf/wct_np, LAPACK SVD) + torch-CPU stand-in for the CPU-TF conv stack; %.2f s per frame '
                       '(min %.2f, max %.2f)' % (size, size, alpha, med, min(times), max(times))}
@@ -127,7 +183,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='weak scaling (default): independent content/style pairs per GPU per step')
     ap.add_argument('--global-batch', type=int, default=0,
                     help='strong scaling: this many pairs per step IN TOTAL, sharded over the GPUs (BASELINE configs[3]: 64 over '
-                         '8 GPUs = 8 per GPU); 0 = weak scaling with --batch pairs per GPU')
+                         '8 GPUs = 8 per GPU); 0 = weak scaling with --batch pairs per GPU (and, for --gpus > 1, a `strong` '
+                         'sub-record with 64 pairs per step in the same line)')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--alpha', type=float, default=0.8)
     ap.add_argument('--shared-style', action='store_true',
@@ -136,6 +193,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 host-in/host-out latency leg')
     ap.add_argument('--no-prof', action='store_true', help='no per-class HIP-event timing inside the timed region')
+    ap.add_argument('--spectrum', choices=['frames', 'graded'], default='frames',
+                    help="'graded': only the eigensolver's hard-spectrum leg (graded 512-channel covariances, N = 4096 and "
+                         "N = 256 < C): sweeps and ms")
     args = ap.parse_args()
 
     import torch
@@ -161,91 +221,116 @@ def main():
     from wct_tf_amd.weights import synthetic_weights, synthetic_image
     from wct_tf_amd.dist import shard_range, gather_frames
 
-    weights = synthetic_weights(seed=42)
     ctx = Context(local_rank)
+    if args.spectrum == 'graded':
+        if rank == 0:
+            print(json.dumps({'metric': 'eigensolver on graded covariances (wct_transform, one pair)', 'unit': 'ms',
+                              'hard_spectrum': hard_spectrum_leg(ctx), 'sweep_budget': 16}), flush=True)
+        ctx.close()
+        return
+    weights = synthetic_weights(seed=42)
     ctx.set_weights(weights)
 
     S = args.size
-    strong = args.global_batch > 0
-    total_pairs = args.global_batch if strong else args.batch * world
-    lo, hi = shard_range(total_pairs, world, rank)                         # contiguous shard of the global batch
-    n_local = hi - lo
-    content = np.stack([synthetic_image(1000 + i, S, S) for i in range(lo, hi)]) if n_local else np.zeros((0, S, S, 3), np.uint8)
-    style = np.stack([synthetic_image(2000 + i, S, S) for i in range(lo, hi)]) if n_local else np.zeros((0, S, S, 3), np.uint8)
-    if args.shared_style:
-        style = style[:1]
     dev = torch.device('cuda', local_rank)
-    d_content = torch.from_numpy(content).to(dev)                          # inputs resident in HBM
-    d_style = torch.from_numpy(style).to(dev)
-    # two output buffers: the gather of step k reads one while step k+1 writes the other
-    d_out = [torch.empty_like(d_content), torch.empty_like(d_content)]
-    torch.cuda.synchronize()
-
     import ctypes as C
     LIB_MAX = 32                                                            # pairs per library call
-    chunks = [(a, min(n_local, a + LIB_MAX)) for a in range(0, n_local, LIB_MAX)]
     frame_bytes = S * S * 3
-
-    def compute(out):
-        for a, b in chunks:
-            sp = d_style.data_ptr() if args.shared_style else d_style.data_ptr() + a * frame_bytes
-            ctx.stylize_batch_dev(C.c_void_p(d_content.data_ptr() + a * frame_bytes), S, S, C.c_void_p(sp), S, S, b - a, LEVELS,
-                                  args.alpha, C.c_void_p(out.data_ptr() + a * frame_bytes), shared_style=args.shared_style)
-
     # WCT_BENCH_FORCE_OVERLAP=1: run the event protocol of the overlapped gather on a single rank too (tests)
     overlap = (world > 1 and backend == 'nccl') or bool(os.environ.get('WCT_BENCH_FORCE_OVERLAP'))
-    if overlap:
-        # the library's stream as a torch stream: events order the RCCL gather behind the frames and the next write of
-        # a buffer behind the gather that still reads it -- no host synchronisation between the steps
-        lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
-        comm = torch.cuda.Stream(dev)
-        done_compute = [torch.cuda.Event(), torch.cuda.Event()]
-        done_gather = [torch.cuda.Event(), torch.cuda.Event()]
-    state = {'k': 0, 'frames': None}
 
-    def step():
-        k = state['k'] & 1
-        state['k'] += 1
-        if not overlap:
-            compute(d_out[k])
-            if world > 1:                                                  # dry run: stage through the host (gloo)
-                ctx.sync()
-                state['frames'] = gather_frames(d_out[k].cpu(), world, rank, n_items=total_pairs)
-            return
-        lib_stream.wait_event(done_gather[k])                              # buffer k was last read by the gather two steps ago
-        compute(d_out[k])
-        done_compute[k].record(lib_stream)
-        comm.wait_event(done_compute[k])
-        with torch.cuda.stream(comm):                                      # overlaps the next step's kernels
-            state['frames'] = gather_frames(d_out[k], world, rank, n_items=total_pairs)
-            done_gather[k].record(comm)
-
-    def barrier():
-        ctx.sync()
+    def measure(total_pairs, steps, warmup, prof_on):
+        """`steps` timed steps of `total_pairs` pairs per step sharded over the ranks: (seconds [max over ranks], pairs
+        of this rank, per-class profile or None, eigensolver statistics or None)"""
+        lo, hi = shard_range(total_pairs, world, rank)                     # contiguous shard of the global batch
+        n_local = hi - lo
+        content = np.stack([synthetic_image(1000 + i, S, S) for i in range(lo, hi)]) if n_local else np.zeros((0, S, S, 3), np.uint8)
+        style = np.stack([synthetic_image(2000 + i, S, S) for i in range(lo, hi)]) if n_local else np.zeros((0, S, S, 3), np.uint8)
+        if args.shared_style:
+            style = style[:1]
+        d_content = torch.from_numpy(content).to(dev)                      # inputs resident in HBM
+        d_style = torch.from_numpy(style).to(dev)
+        # two output buffers: the gather of step k reads one while step k+1 writes the other
+        d_out = [torch.empty_like(d_content), torch.empty_like(d_content)]
         torch.cuda.synchronize()
+        chunks = [(a, min(n_local, a + LIB_MAX)) for a in range(0, n_local, LIB_MAX)]
+
+        def compute(out):
+            for a, b in chunks:
+                sp = d_style.data_ptr() if args.shared_style else d_style.data_ptr() + a * frame_bytes
+                ctx.stylize_batch_dev(C.c_void_p(d_content.data_ptr() + a * frame_bytes), S, S, C.c_void_p(sp), S, S, b - a, LEVELS,
+                                      args.alpha, C.c_void_p(out.data_ptr() + a * frame_bytes), shared_style=args.shared_style)
+
+        if overlap:
+            # the library's stream as a torch stream: events order the RCCL gather behind the frames and the next write of
+            # a buffer behind the gather that still reads it -- no host synchronisation between the steps
+            lib_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=dev)
+            comm = torch.cuda.Stream(dev)
+            done_compute = [torch.cuda.Event(), torch.cuda.Event()]
+            done_gather = [torch.cuda.Event(), torch.cuda.Event()]
+        state = {'k': 0, 'frames': None}
+
+        def step():
+            k = state['k'] & 1
+            state['k'] += 1
+            if not overlap:
+                compute(d_out[k])
+                if world > 1:                                              # dry run: stage through the host (gloo)
+                    ctx.sync()
+                    state['frames'] = gather_frames(d_out[k].cpu(), world, rank, n_items=total_pairs)
+                return
+            lib_stream.wait_event(done_gather[k])                          # buffer k was last read by the gather two steps ago
+            compute(d_out[k])
+            done_compute[k].record(lib_stream)
+            comm.wait_event(done_compute[k])
+            with torch.cuda.stream(comm):                                  # overlaps the next step's kernels
+                state['frames'] = gather_frames(d_out[k], world, rank, n_items=total_pairs)
+                done_gather[k].record(comm)
+
+        def barrier():
+            ctx.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        ctx.eig_stats()                                                    # clear
+        if prof_on:
+            ctx.prof_reset()
+            ctx.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        ctx.prof_enable(False)
         if world > 1:
-            dist.barrier()
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            if rank == 0:
+                assert state['frames'] is not None and state['frames'].shape[0] == total_pairs
+        prof = ctx.prof_read() if prof_on else None
+        return dt, n_local, prof, ctx.eig_stats()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    strong = args.global_batch > 0
+    total_pairs = args.global_batch if strong else args.batch * world
+    dt, n_local, prof, eig = measure(total_pairs, args.steps, args.warmup, not args.no_prof)
+    # the same steps without the per-class events (they cost 1-2 %): reported beside the headline, never instead of it
+    dt_np = None
     if not args.no_prof:
-        ctx.prof_reset()
-        ctx.prof_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        if rank == 0:
-            assert state['frames'] is not None and state['frames'].shape[0] == total_pairs
+        dt_np = measure(total_pairs, args.steps, 1, False)[0]
+    # N > 1, weak headline: BASELINE configs[3] as written (64 pairs per step in total) in the same line
+    strong_rec = None
+    if world > 1 and not strong:
+        g = 64
+        dts, _, _, _ = measure(g, args.steps, args.warmup, False)
+        strong_rec = {'global_batch': g, 'pairs_per_gpu_per_step': g / world, 'value': g * args.steps / dts, 'unit': 'frames/s',
+                      'ms_per_step': 1e3 * dts / args.steps, 'scaling': 'strong',
+                      'note': 'BASELINE configs[3]: 64 frames per step sharded over the GPUs, one RCCL gather per step'}
 
-    prof = None if args.no_prof else ctx.prof_read()
     if rank == 0:
         frames = total_pairs * args.steps
         fps = frames / dt
@@ -264,6 +349,11 @@ def main():
                                       + ', no data-path collective, one RCCL gather of the uint8 frames per step overlapped with the next step',
                        'weights': 'synthetic He-normal seed 42 (no pre-trained weights offline)'},
         }
+        if dt_np is not None:
+            line['no_prof'] = {'value': frames / dt_np, 'unit': 'frames/s', 'ms_per_step': 1e3 * dt_np / args.steps,
+                               'note': 'the same %d steps timed again without the per-class HIP events' % args.steps}
+        if strong_rec is not None:
+            line['strong'] = strong_rec
         if prof is not None:
             conv = prof['conv3x3']
             ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
@@ -281,14 +371,24 @@ def main():
             }
             step_ms = 1e3 * dt / args.steps
             jac = prof['jacobi']
+            jflops = sum(v['sweeps'] * jacobi_flops_per_sweep(c) for c, v in eig.items())
+            jtf = jflops / (jac['ms'] * 1e-3) / 1e12 if jac['ms'] > 0 else 0.0
             line['eigensolver'] = {
                 'ms_per_step': jac['ms'] / args.steps, 'share_of_step': jac['ms'] / args.steps / step_ms,
-                'matrices_per_step': 2 * 5 * n_local, 'bound': 'latency of the serial rotation sets + fp32-MFMA tile updates',
+                'matrices_per_step': 2 * 5 * n_local,
+                'sweeps': {str(c): {'mean': v['sweeps'] / max(1, v['matrices']), 'max': v['max_sweeps'], 'budget': 16} for c, v in sorted(eig.items())},
+                'achieved_tflops': jtf, 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'frac_of_f32_mfma_peak': jtf / F32_MFMA_PEAK_TFLOPS,
+                'flops_note': 'fp32-MFMA FLOPs of the tile updates the sweeps executed (two-sided A tiles + V Q), from the sweep '
+                              'counts the library reports (wct_eig_stats); the rotation sets themselves run on the VALU/LDS',
+                'bound': 'latency of the serial rotation sets (LDS write path) + fp32-MFMA tile updates',
                 'note': 'batched two-sided block Jacobi on the %d-level covariances (C = 512, 512, 256, 128, 64; content and style); '
-                        'second-largest time class' % len(LEVELS)}
+                        'look-ahead launches {pair problems of step s, tile update of step s-1}, V resident in registers per '
+                        'launch segment from 8 matrices on; second-largest time class' % len(LEVELS)}
             line['breakdown_ms_per_step'] = {k: v['ms'] / args.steps for k, v in prof.items()}
         if world == 1 and not args.no_latency and not args.shared_style:
             line.update(latency_leg(ctx, S, args.alpha))
+            if 'eigensolver' in line:
+                line['eigensolver']['hard_spectrum'] = hard_spectrum_leg(ctx)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(S, weights, args.alpha)
         print(json.dumps(line), flush=True)

@@ -183,6 +183,10 @@ int wct_prof_enable(wct_ctx* ctx, int on);
 int wct_prof_reset(wct_ctx* ctx);
 int wct_prof_read(wct_ctx* ctx, double ms[WCT_PROF_CLASSES], long long launches[WCT_PROF_CLASSES],
                   double flops[WCT_PROF_CLASSES], double bytes[WCT_PROF_CLASSES]);
+/* Eigensolver statistics since the last call (the decompositions that replace tf.svd / np.linalg.svd, ops.py:53-55,
+ * 110,123), per size class k = 0..5 (covariances of order 32 * 2^k): out[3k] = matrices solved, out[3k+1] = sum of
+ * the sweeps they took, out[3k+2] = the largest sweep count.  Synchronises the ctx stream; cleared on read. */
+int wct_eig_stats(wct_ctx* ctx, long long out[18]);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,10 @@ class TorchPath(object):
                 x = F.interpolate(x, scale_factor=2, mode='nearest')
         return x
 
-    def stylize(self, content, style, relu_targets, alpha=1.0, wct_mode='tf'):
+    def stylize(self, content, style, relu_targets, alpha=1.0, wct_mode='tf', timers=None):
+        """timers (optional dict): receives 'transform_s', the seconds spent in the NumPy transforms of this call"""
+        import time
+        t_transform = 0.0
         to_t = lambda img: torch.from_numpy(np.float32(preprocess(img)).transpose(2, 0, 1)[None])     # noqa: E731
         to_np = lambda t: t[0].permute(1, 2, 0).numpy()                                                # noqa: E731
         with torch.no_grad():
@@ -72,6 +75,10 @@ class TorchPath(object):
                     x = torch.clamp(x, 0, 1)                # model.py:86
                 fc = to_np(self.encode(x, [relu])[relu])
                 fs = to_np(sfeat[relu])
+                t0 = time.time()
                 t = (wct_oracle.wct_tf if wct_mode == 'tf' else wct_oracle.wct_np)(fc, fs, alpha)
+                t_transform += time.time() - t0
                 x = self.decode(torch.from_numpy(np.ascontiguousarray(t[0].transpose(2, 0, 1)))[None], relu)
+        if timers is not None:
+            timers['transform_s'] = t_transform
         return postprocess(to_np(x))

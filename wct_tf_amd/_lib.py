@@ -56,6 +56,7 @@ SIGNATURES = [
     ('wct_prof_enable', C.c_int, [_P, C.c_int]),
     ('wct_prof_reset', C.c_int, [_P]),
     ('wct_prof_read', C.c_int, [_P, _D, C.POINTER(C.c_longlong), _D, _D]),
+    ('wct_eig_stats', C.c_int, [_P, C.POINTER(C.c_longlong)]),
 ]
 
 WCT_NP, WCT_TF = 0, 1

@@ -325,6 +325,14 @@ class Context(object):
         return {name: {'ms': ms[i], 'launches': cnt[i], 'flops': fl[i], 'bytes': by[i]}
                 for i, name in enumerate(_lib.PROF_CLASSES)}
 
+    def eig_stats(self):
+        """Eigensolver statistics since the last call: {C: {'matrices', 'sweeps', 'max_sweeps'}} for the covariance
+        orders C = 32 * 2^k that were solved (wct_eig_stats; synchronises the stream, cleared on read)."""
+        out = (C.c_longlong * 18)()
+        check(self.lib.wct_eig_stats(self.h, out))
+        return {32 << k: {'matrices': out[3 * k], 'sweeps': out[3 * k + 1], 'max_sweeps': out[3 * k + 2]}
+                for k in range(6) if out[3 * k]}
+
 
 _default = {}
 

@@ -53,6 +53,7 @@ struct Decoder {
 };
 
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+constexpr int WCT_EIG_WORDS = 8 + 4 * 6 * 3;
 
 struct wct_ctx {
   int device = 0;
@@ -69,7 +70,8 @@ struct wct_ctx {
   DevBuf train_ws;
   Decoder dec[6];
   DevBuf act[2], feat_c, feat_s[6], img_c, img_s, img_t[2], wct_out, wct_ws, stage[4];
-  int* eig_fail = nullptr;         // pinned host memory mapped into the device, [4 stream groups][2]: eigenproblems that did
+  int* eig_fail = nullptr;         // pinned host memory mapped into the device: [4 stream groups][2] eigenproblems that did
+                                   // (then [4 groups][6 size classes][3] solver statistics: matrices, sweeps, max sweeps)
   int* eig_fail_dev = nullptr;     // not converge / had non-finite input -- bumped by jacobi_finalize_kernel
   float ss_alpha = 0.6f;           // style-swap settings (stylize.py:34-37 defaults)
   int ss_patch = 3, ss_stride = 1;
@@ -151,14 +153,14 @@ extern "C" int wct_create(int device, wct_ctx** out) {
     delete c;
     return WCT_ERR_HIP;
   }
-  if (ok) ok = hipHostMalloc((void**)&c->eig_fail, 8 * sizeof(int), hipHostMallocMapped) == hipSuccess &&
+  if (ok) ok = hipHostMalloc((void**)&c->eig_fail, WCT_EIG_WORDS * sizeof(int), hipHostMallocMapped) == hipSuccess &&
                hipHostGetDevicePointer((void**)&c->eig_fail_dev, c->eig_fail, 0) == hipSuccess;
   if (!ok) {
     wct_set_error("hipHostMalloc (mapped status words) failed");
     delete c;
     return WCT_ERR_HIP;
   }
-  for (int i = 0; i < 8; ++i) c->eig_fail[i] = 0;
+  for (int i = 0; i < WCT_EIG_WORDS; ++i) c->eig_fail[i] = 0;
   if (const char* e = getenv("WCT_EIG_GROUPS")) { int n = atoi(e); c->nside = n < 1 ? 0 : (n > 4 ? 3 : n - 1); }
   *out = c;
   return WCT_OK;
@@ -219,6 +221,22 @@ extern "C" int wct_sync(wct_ctx* c) {
   ARG_CHECK(c != nullptr);
   HIP_TRY(hipStreamSynchronize(c->stream));
   return eig_status(c);
+}
+
+// Solver statistics since the last call (after a stream sync), per size class k (matrices of order 32 * 2^k, k = 0..5):
+// out[3k] = matrices solved, out[3k+1] = sum of their sweeps, out[3k+2] = the largest sweep count.  Cleared on read.
+extern "C" int wct_eig_stats(wct_ctx* c, long long out[18]) {
+  ARG_CHECK(c && out);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 18; ++k) out[k] = 0;
+  for (int g = 0; g < 4; ++g)
+    for (int k = 0; k < 6; ++k) {
+      int* s = c->eig_fail + 8 + (g * 6 + k) * 3;
+      out[3 * k] += s[0]; out[3 * k + 1] += s[1];
+      if (s[2] > out[3 * k + 2]) out[3 * k + 2] = s[2];
+      s[0] = s[1] = s[2] = 0;
+    }
+  return WCT_OK;
 }
 
 extern "C" int wct_get_stream(wct_ctx* c, void** stream_out) {

@@ -1605,7 +1605,10 @@ __global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, i
 // fail: this group's slot of the caller's status words (host memory mapped into the device, one slot per stream
 // group so that plain read-modify-writes of one thread suffice), read by the caller after its next stream sync --
 // a failed solve is never silently dropped.
-__global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, int nmat, float tol_max, float tol_fn, volatile int* fail, int debug) {
+// stats (or null): this group's slot of the caller's solver statistics (host memory mapped into the device):
+// [0] matrices solved, [1] sum of their sweeps, [2] the largest sweep count -- wct_eig_stats reads and clears them
+__global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, int nmat, float tol_max, float tol_fn, volatile int* fail, int debug,
+                                       volatile int* stats = nullptr) {
   const int m = threadIdx.x;
   int d = m < nmat ? st[m].done : 1;
   if (debug && m < nmat)
@@ -1620,9 +1623,15 @@ __global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, i
     if (n_open) fail[0] = fail[0] + n_open;
     if (n_nan) fail[1] = fail[1] + n_nan;
   }
+  if (stats) {
+    int sw = m < nmat ? st[m].sweeps : 0;                  // 0: a matrix that was never rotated (shared style)
+    int cnt = sw > 0 ? 1 : 0, mx = sw;
+    for (int o = 32; o > 0; o >>= 1) { sw += __shfl_xor(sw, o, 64); cnt += __shfl_xor(cnt, o, 64); mx = max(mx, __shfl_xor(mx, o, 64)); }
+    if (m == 0) { stats[0] = stats[0] + cnt; stats[1] = stats[1] + sw; if (mx > stats[2]) stats[2] = mx; }
+  }
 }
 
-constexpr int JACOBI_MAX_SWEEPS = 12;
+constexpr int JACOBI_MAX_SWEEPS = 16;   // round 3: 12 -> 16 (graded rank-deficient 512-channel spectra used 10-12; a failure stays loud)
 // WCT_JACOBI_MAX_SWEEPS (read at every solve): lowers the sweep budget so that the non-convergence path can be tested
 static int jacobi_max_sweeps() {
   const char* e = getenv("WCT_JACOBI_MAX_SWEEPS");
@@ -1652,6 +1661,7 @@ struct JacobiGroup {
   int mat0, shared_style;      // position in a WCT batch (skip_style_mat); 0, 0 for a plain batch
   float tol_fn;                // > 0: also stop on the measured residual (callers that complete f(A) to first order)
   int* fail;                   // device view of this group's slot [2] of the caller's status words, or null
+  int* stats;                  // device view of this group's statistics slot [3] for matrices of this size class, or null
 };
 
 // per host thread (= per ctx user): pinned copies of the groups' convergence flags and one event per group
@@ -1761,8 +1771,8 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
     }
   }
   for (int g = 0; g < ngrp; ++g)
-    if (grp[g].sweeps_out || grp[g].fail)
-      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].fail, getenv("WCT_JACOBI_DEBUG") != nullptr);
+    if (grp[g].sweeps_out || grp[g].fail || grp[g].stats)
+      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].fail, getenv("WCT_JACOBI_DEBUG") != nullptr, grp[g].stats);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
@@ -1947,15 +1957,15 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     for (int l = 0; l < 2; ++l)            // the V passes still in flight belong to this solve
       if (G.vstrip && G.v_busy[l]) { HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_v[l], 0)); G.v_busy[l] = false; }
     hipLaunchKernelGGL(jacobi_gather_kernel, dim3(32, G.nmat), dim3(256), 0, G.stream, G.A, G.P[1], G.st, C, G.cur);
-    if (G.sweeps_out || G.fail)
-      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, G.stream, G.st, G.sweeps_out, G.nmat, conv_tol, G.tol_fn, G.fail, getenv("WCT_JACOBI_DEBUG") != nullptr);
+    if (G.sweeps_out || G.fail || G.stats)
+      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, G.stream, G.st, G.sweeps_out, G.nmat, conv_tol, G.tol_fn, G.fail, getenv("WCT_JACOBI_DEBUG") != nullptr, G.stats);
   }
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
 
 static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
-                             int* sweeps_out, int* fail, hipStream_t s) {
+                             int* sweeps_out, int* fail, hipStream_t s, int* stats = nullptr) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
   ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
   const size_t cc = (size_t)C * C;
@@ -1968,7 +1978,7 @@ static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat
   G->st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
   G->resid = reinterpret_cast<float*>(reinterpret_cast<char*>(G->st) + (((size_t)nmat * sizeof(JacobiState) + 255) / 256) * 256);
   G->tol_fn = 0.f;
-  G->stream = s; G->sweeps_out = sweeps_out; G->fail = fail;
+  G->stream = s; G->sweeps_out = sweeps_out; G->fail = fail; G->stats = stats;
   G->mat0 = 0; G->shared_style = 0;
   return WCT_OK;
 }
@@ -1985,10 +1995,19 @@ static int jacobi_dispatch(JacobiGroup* grp, int ngrp, int C) {
   return m64 ? jacobi_run_groups<64>(grp, ngrp, C) : jacobi_run_groups<32>(grp, ngrp, C);
 }
 
+// statistics slot of stream group g for matrices of order C inside the caller's status words: after the 8 failure
+// words come [4 groups][6 size classes][3] counters (size class = log2(C / 32), capped)
+static int* jacobi_stats_slot(int* eig_fail, int g, int C) {
+  if (!eig_fail) return nullptr;
+  int cls = 0;
+  for (int c = C / 32; c > 1 && cls < 5; c >>= 1) ++cls;
+  return eig_fail + 8 + (g * 6 + cls) * 3;
+}
+
 int launch_jacobi_eigh(float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
                        int* sweeps_done_dev, int* eig_fail, hipStream_t s) {
   JacobiGroup G;
-  int rc = jacobi_make_group(&G, A, V, C, nmat, workspace, workspace_bytes, sweeps_done_dev, eig_fail, s);
+  int rc = jacobi_make_group(&G, A, V, C, nmat, workspace, workspace_bytes, sweeps_done_dev, eig_fail, s, jacobi_stats_slot(eig_fail, 0, C));
   if (rc) return rc;
   return jacobi_dispatch(&G, 1, C);
 }
@@ -2415,7 +2434,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
         hipStream_t sg = g == 0 ? s : side[g - 1];
         if (g > 0) HIP_TRY(hipStreamWaitEvent(sg, ev_fork, 0));
         if ((rc = jacobi_make_group(&grp[g], w.A + (size_t)m0 * cc, w.V + (size_t)m0 * cc, C, n, (char*)w.jacobi_ws + off,
-                                    bytes, sweeps_dev ? sweeps_dev + m0 : nullptr, eig_fail ? eig_fail + 2 * g : nullptr, sg))) return rc;
+                                    bytes, sweeps_dev ? sweeps_dev + m0 : nullptr, eig_fail ? eig_fail + 2 * g : nullptr, sg, jacobi_stats_slot(eig_fail, g, C)))) return rc;
         grp[g].mat0 = m0; grp[g].shared_style = shared_style; grp[g].tol_fn = jacobi_tol_fn();
         off += bytes; m0 += n;
       }
@@ -2426,7 +2445,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       }
     } else {
       JacobiGroup G;
-      if ((rc = jacobi_make_group(&G, w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, eig_fail, s))) return rc;
+      if ((rc = jacobi_make_group(&G, w.A, w.V, C, 2 * P, w.jacobi_ws, w.jacobi_bytes, sweeps_dev, eig_fail, s, jacobi_stats_slot(eig_fail, 0, C)))) return rc;
       G.shared_style = shared_style; G.tol_fn = jacobi_tol_fn();
       if ((rc = jacobi_dispatch(&G, 1, C))) return rc;
     }
