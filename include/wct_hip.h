@@ -47,9 +47,12 @@ enum wct_flags {
   WCT_FLAG_ADAIN = 1,      /* --adain: AdaIN at every level instead of WCT (model.py:148-158) */
   WCT_FLAG_MODE_NP = 2,    /* use wct_np semantics instead of the graph's wct_tf */
   WCT_FLAG_SWAP5 = 4,      /* --swap5: style-swap at relu5_1 (wins over ADAIN there, model.py:148-152) */
-  WCT_FLAG_STYLE_SHARED = 8 /* wct_stylize_batch_dev only: `style` is ONE image shared by all B pairs (stylize_video.py
+  WCT_FLAG_STYLE_SHARED = 8, /* wct_stylize_batch_dev only: `style` is ONE image shared by all B pairs (stylize_video.py
                               keeps one style for every frame but re-runs it per frame, stylize_video.py:88-106);
                               the style pass, statistics and eigensystems run once per call, results are identical */
+  WCT_FLAG_IMAGES_F32 = 16  /* content / style point at float32 images already in [0,1] (WCT.preprocess applied by the
+                              caller: a FLOAT input of predict() is divided by 255 without rounding, wct.py:60-64)
+                              instead of uint8 ones; the output stays uint8 */
 };
 
 /* ---- lifecycle: replaces WCT.__init__'s tf.Session setup (wct.py:29-44) ---- */

@@ -82,6 +82,52 @@ def in_probe(x):
     return np.array([x.sum(), (x * x).sum(), x.reshape(-1)[::9973].sum()])
 
 
+# Hard 512-channel spectra: the reference's own wct_np on (a) a covariance graded over 5 decades at
+# N = 4096 (eigenvalues ~5e1 .. 5e-4: all kept -- a graded spectrum that runs THROUGH the 1e-5 cut-off puts a mode
+# within fp32 noise of it, where the reference's own keep/drop decision is a coin toss; that situation is covered by the
+# fuzz tests' kept-count band), (b) 6 decades with N = 256 < C (rank-deficient by size: the null space is rounding
+# noise, the 255 kept eigenvalues end at ~1e-4), (c) the
+# relu5_1 shape of a 256x256 input (16x16 pixels, 512 channels) with 4-decade channel scales.  Digest fixtures like
+# SIZE_CASES: inputs are rebuilt from their seeds (float64 arithmetic, then one cast), in_probe pins the rebuild.
+HARD512_CASES = [
+    # name, C, h, w, alpha, content seed, style seed, kind
+    ('c512_graded5_n4096', 512, 64, 64, 0.8, 7301, 7401, 'graded5'),
+    ('c512_graded6_n256', 512, 16, 16, 0.8, 7302, 7402, 'graded6'),
+    ('c512_relu5_of_256px_n256', 512, 16, 16, 0.8, 7303, 7403, 'mixed4'),
+]
+
+
+def graded_features_exact(seed, c, n, decades, amp=3.0):
+    """post-ReLU-like [n][c] features with a graded covariance: per-channel scales log-spaced over decades/2, mild
+    channel mixing (float64 throughout, one cast at the end)"""
+    rng = np.random.default_rng(seed)
+    mix = np.eye(c) + 0.3 * rng.standard_normal((c, c)) / np.sqrt(c)
+    d = 10.0 ** (-np.arange(c) * decades / (c - 1) / 2)
+    return np.float32(np.maximum(rng.standard_normal((n, c)) @ mix + 0.3, 0) * d * amp)
+
+
+def hard512_inputs(case):
+    name, c, h, w, alpha, sc, ss, kind = case
+    if kind in ('graded5', 'graded6'):
+        dec, amp = (5.0, 9.0) if kind == 'graded5' else (6.0, 3.0)
+        return (graded_features_exact(sc, c, h * w, dec, amp).reshape(1, h, w, c),
+                graded_features_exact(ss, c, h * w, dec, amp).reshape(1, h, w, c))
+    return synthetic_features_exact(sc, c, h, w, 4.0), synthetic_features_exact(ss, c, h, w, 4.0)
+
+
+# wct_tf (ops.py:24-90, the transform the live graph runs) pinned through the reference's own code: TensorFlow cannot
+# be imported, but wct_np(content, style, alpha, eps=0) differs from wct_tf only by (1) the content mean that wct_tf
+# restores in the blend (ops.py:83 vs :133) and (2) the 1e-8 wct_tf adds to the covariance diagonals (ops.py:45,50),
+# which moves a gain lambda^-+1/2 by 0.5e-8 / lambda relatively.  So  ref_wct_np(c, s, alpha, eps=0) + (1 - alpha) mc
+# is the wct_tf output to within that bound; the fixture stores it with the smallest kept eigenvalues.
+WCT_TF_CASES = [
+    # name, C, (hc, wc), (hs, ws), alpha, decades
+    ('tf_c64', 64, (24, 20), (16, 28), 0.8, 2.0),
+    ('tf_c128_alpha06', 128, (20, 20), (24, 16), 0.6, 2.0),
+    ('tf_c256_alpha1', 256, (24, 24), (20, 28), 1.0, 1.5),
+]
+
+
 def hard_feature_cases():
     """Feature maps with the defects real VGG features have and Gaussian-mixed ones do not (hard parts
     2 and 5): channels that are exactly dead, exactly duplicated channels, post-ReLU sparsity."""
@@ -121,6 +167,7 @@ def gilbert_fixture():
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref_wct_np = lift_function(os.path.join(REF, 'ops.py'), 'wct_np')
+    ref_wct_np(np.zeros((1, 2, 2, 32), np.float32) + np.arange(32, dtype=np.float32), np.ones((1, 2, 2, 32), np.float32), 0.5, 0.0)   # signature: (content, style, alpha, eps)
 
     # ---- the reference at the metric's own WCT shapes (digests) ----
     blob = {}
@@ -157,6 +204,43 @@ def main():
         blob['gilbert_' + relu + '/alpha'] = np.float64(0.8)
         blob['gilbert_' + relu + '/out'] = ref_wct_np(fc, fs, 0.8)
     np.savez_compressed(os.path.join(OUT, 'wct_np_hard.npz'), **blob)
+
+    # ---- hard 512-channel spectra (digests) ----
+    blob = {}
+    for case in HARD512_CASES:
+        name, c, h, w, alpha = case[:5]
+        fc, fs = hard512_inputs(case)
+        out = ref_wct_np(fc, fs, alpha)
+        o = out.reshape(h * w, c)
+        rows, signs = digest_selectors(case[:7])
+        blob[name + '/rows'] = o[rows]
+        blob[name + '/sketch'] = signs @ o.astype(np.float64)
+        blob[name + '/mean'] = o.astype(np.float64).mean(0)
+        blob[name + '/sq'] = (o.astype(np.float64) ** 2).mean(0)
+        blob[name + '/in_probe'] = np.stack([in_probe(fc), in_probe(fs)])
+        ev = np.linalg.eigvalsh(np.cov(fc.reshape(-1, c).astype(np.float64).T))
+        blob[name + '/content_eig_max_min_kept'] = np.array([ev.max(), ev[ev > 1e-5].min(), (ev > 1e-5).sum()])
+        print(name, 'content eigenvalues %.2e .. %.2e kept %d' % (ev.max(), max(ev.min(), 1e-30), (ev > 1e-5).sum()))
+    np.savez_compressed(os.path.join(OUT, 'wct_np_hard512.npz'), **blob)
+
+    # ---- wct_tf through the reference's wct_np(eps=0) ----
+    blob = {}
+    for i, (name, c, (hc, wc), (hs, ws), alpha, dec) in enumerate(WCT_TF_CASES):
+        content = synthetic_features(500 + i, c, hc, wc, dec)
+        style = synthetic_features(600 + i, c, hs, ws, dec)
+        lam = []
+        for f in (content, style):
+            ev = np.linalg.eigvalsh(np.cov(f.reshape(-1, c).astype(np.float64).T))
+            assert not np.any((ev > 0.5e-5) & (ev < 2e-5)), name       # nothing near the cut-off: the 1e-8 cannot flip a mode
+            lam.append(ev[ev > 1e-5].min())
+        out = ref_wct_np(content, style, alpha, 0.0)
+        mc = content.reshape(-1, c).mean(0, dtype=np.float32)
+        blob[name + '/content'], blob[name + '/style'] = content, style
+        blob[name + '/alpha'] = np.float64(alpha)
+        blob[name + '/out'] = np.float32(out + np.float32(1 - alpha) * mc)
+        blob[name + '/lam_min'] = np.array(lam)
+        print(name, 'smallest kept eigenvalues', lam)
+    np.savez_compressed(os.path.join(OUT, 'wct_tf_reference.npz'), **blob)
 
     blob = {}
     for i, (name, c, (hc, wc), (hs, ws), alpha, dec, rank) in enumerate(WCT_CASES):

@@ -59,6 +59,62 @@ def test_wct_np_matches_reference_at_config_sizes():
         print(case[0], check_against_size_digest(z, case, out, 1e-5))
 
 
+def test_wct_np_matches_reference_on_hard_512_channel_spectra():
+    """512-channel covariances graded over 5 decades at N = 4096, and N = 256 < C (a 6-decade grading, and
+    the relu5_1 shape of a 256x256 input) -- the reference's own wct_np outputs (digests)."""
+    from oracle.make_golden import HARD512_CASES, hard512_inputs, in_probe
+    z = np.load(os.path.join(GOLDEN, 'wct_np_hard512.npz'))
+    for case in HARD512_CASES:
+        fc, fs = hard512_inputs(case)
+        assert np.allclose(np.stack([in_probe(fc), in_probe(fs)]), z[case[0] + '/in_probe'], rtol=1e-6)
+        out = oracle.wct_np(fc, fs, case[4])
+        print(case[0], z[case[0] + '/content_eig_max_min_kept'], check_against_size_digest(z, case[:7], out, 1e-5))
+
+
+def test_wct_tf_is_pinned_by_the_reference_wct_np_without_eps():
+    """ops.py:24-90 cannot run (TensorFlow), but ops.py:92-140 can: wct_np(c, s, alpha, eps=0) + (1 - alpha) mc is
+    wct_tf up to the 1e-8 that wct_tf adds to the covariance diagonals (ops.py:45,50), i.e. up to 0.5e-8 / lambda_min
+    relative in the gains (fixture: oracle/make_golden.py WCT_TF_CASES, run on the reference's own code)."""
+    z, names = _cases('wct_tf_reference.npz')
+    assert len(names) == 3
+    for n in names:
+        got = oracle.wct_tf(z[n + '/content'], z[n + '/style'], float(z[n + '/alpha']))
+        ref = z[n + '/out']
+        bound = 2e-5 + 1e-8 / float(z[n + '/lam_min'].min())
+        print(n, 'rel %.2e (bound %.2e)' % (rel_err(got, ref), bound))
+        assert got.shape == ref.shape and rel_err(got, ref) < bound and max_rel(got, ref) < 10 * bound, n
+
+
+def test_contractive_weight_set_is_well_conditioned():
+    """The end-to-end GPU test (tests/test_gpu_pipeline.py) runs the five-level chain on oracle.contractive weights;
+    this is why it can: one flipped input bit moves the oracle's own output by (almost) nothing, and the oracle with
+    this path's fp16 storage stays within a few LSB of the fp32 oracle -- against ~30 LSB for both on the He-normal
+    weights (test_five_level_chain_is_chaotic_on_random_weights)."""
+    from oracle.contractive import contractive_weights
+    w = contractive_weights(7)
+    c = synthetic_image(1000, 96, 96)
+    s = synthetic_image(2000, 96, 96)
+    targets = ['relu5_1', 'relu4_1', 'relu3_1', 'relu2_1', 'relu1_1']
+    a = oracle.stylize(c, s, w, targets, alpha=0.8)
+    c2 = c.copy()
+    c2[48, 48, 0] ^= 1
+    b = oracle.stylize(c2, s, w, targets, alpha=0.8)
+    a16 = oracle.stylize(c, s, w, targets, alpha=0.8, fp16_storage=True)
+    d, d16 = np.abs(a.astype(int) - b.astype(int)), np.abs(a.astype(int) - a16.astype(int))
+    print('one-bit flip: mean %.4f max %d LSB; fp16 storage: mean %.3f max %d LSB; image std %.1f' % (d.mean(), d.max(), d16.mean(), d16.max(), a.std()))
+    assert d.mean() < 0.1 and d.max() <= 2 and d16.mean() < 3 and a.std() > 15
+
+
+def test_float_images_are_preprocessed_like_the_reference():
+    """wct.py:60-64: predict() divides whatever array it is given by 255 -- a FLOAT image is not rounded to integer
+    levels.  The host side of the float path (Context.stylize) must hand over exactly float32(image / 255.)."""
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 255, (5, 7, 3))
+    want = np.float32(oracle.preprocess(img))
+    assert np.array_equal(np.ascontiguousarray(np.asarray(img / 255.), np.float32), want)
+    assert not np.array_equal(np.float32(np.uint8(img) / 255.), want)
+
+
 def test_coral_matches_reference_outputs():
     z, names = _cases('coral_reference.npz')
     for n in names:

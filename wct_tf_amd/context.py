@@ -197,15 +197,24 @@ class Context(object):
         check(self.lib.wct_output_size(hc, wc, arr, len(lv), C.byref(ho), C.byref(wo)))
         return ho.value, wo.value
 
-    def stylize(self, content_u8, style_u8, relu_targets, alpha=1.0, adain=False, wct_mode='tf', swap5=False):
-        c = u8(content_u8)
-        s = u8(style_u8)
+    def stylize(self, content, style, relu_targets, alpha=1.0, adain=False, wct_mode='tf', swap5=False):
+        """One predict(): HxWx3 images in [0,255] in, uint8 out.  uint8 inputs go to the library as they are (the /255
+        runs on the device); anything else is preprocessed exactly as the reference does -- `image / 255.` in float64
+        (wct.py:60-64), cast to the float32 the graph's placeholders hold (model.py:43-44) -- and handed over as float32
+        images in [0,1] (WCT_FLAG_IMAGES_F32): a float image is NOT rounded to integer levels."""
+        content, style = np.asarray(content), np.asarray(style)
+        as_f32 = content.dtype != np.uint8 or style.dtype != np.uint8
+        if as_f32:
+            c = np.ascontiguousarray(np.asarray(content / 255.), np.float32)
+            s = np.ascontiguousarray(np.asarray(style / 255.), np.float32)
+        else:
+            c, s = u8(content), u8(style)
         lv = _levels(relu_targets)
         arr = (C.c_int * len(lv))(*lv)
         ho, wo = self.output_size(c.shape[0], c.shape[1], lv)
         out = np.empty((ho, wo, 3), np.uint8)
         flags = (_lib.FLAG_ADAIN if adain else 0) | (_lib.FLAG_MODE_NP if wct_mode == 'np' else 0) | \
-            (_lib.FLAG_SWAP5 if swap5 else 0)
+            (_lib.FLAG_SWAP5 if swap5 else 0) | (_lib.FLAG_IMAGES_F32 if as_f32 else 0)
         check(self.lib.wct_stylize(self.h, c.ctypes.data_as(_lib._U8), c.shape[0], c.shape[1],
                                    s.ctypes.data_as(_lib._U8), s.shape[0], s.shape[1], arr, len(lv),
                                    float(alpha), flags, out.ctypes.data_as(_lib._U8)))

@@ -824,12 +824,15 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
   const int Bs = shared ? 1 : B;
   // images to fp32 in [0,1] (wct.py:60-64)
   const size_t nc = (size_t)B * Hc * Wc * 3, ns = (size_t)Bs * Hs * Ws * 3;
-  TRY(ensure(c, c->img_c, nc * 4));
-  TRY(ensure(c, c->img_s, ns * 4));
-  {
+  const float* img_c = reinterpret_cast<const float*>(content);
+  const float* img_s = reinterpret_cast<const float*>(style);
+  if (!(flags & WCT_FLAG_IMAGES_F32)) {
+    TRY(ensure(c, c->img_c, nc * 4));
+    TRY(ensure(c, c->img_s, ns * 4));
     ProfScope ps(c, 7, 0, (double)(nc + ns) * 5);
     TRY(launch_u8_to_f32(content, (float*)c->img_c.p, nc, c->stream));
     TRY(launch_u8_to_f32(style, (float*)c->img_s.p, ns, c->stream));
+    img_c = (const float*)c->img_c.p; img_s = (const float*)c->img_s.p;
   }
   // ONE style pass with a tap per requested level (model.py:69-75)
   float* taps[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -840,9 +843,9 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
     TRY(ensure(c, c->feat_s[l], (size_t)Bs * h * w * LEVEL_C[l] * 4));
     taps[l] = (float*)c->feat_s[l].p;
   }
-  TRY(run_encoder(c, (float*)c->img_s.p, Bs, Hs, Ws, 0, deepest, taps));
+  TRY(run_encoder(c, img_s, Bs, Hs, Ws, 0, deepest, taps));
 
-  const float* cur = (float*)c->img_c.p;
+  const float* cur = img_c;
   int H = Hc, W = Wc;
   for (int i = 0; i < n_levels; ++i) {
     const int l = levels[i], C = LEVEL_C[l];
@@ -889,8 +892,9 @@ extern "C" int wct_stylize(wct_ctx* c, const uint8_t* content, int Hc, int Wc, c
   int Ho, Wo;
   TRY(wct_output_size(Hc, Wc, levels, n_levels, &Ho, &Wo));
   void *dc, *ds;
-  TRY(stage_in(c, 0, content, (size_t)Hc * Wc * 3, &dc));
-  TRY(stage_in(c, 1, style, (size_t)Hs * Ws * 3, &ds));
+  const size_t px = (flags & WCT_FLAG_IMAGES_F32) ? sizeof(float) : 1;       // bytes per colour sample of the inputs
+  TRY(stage_in(c, 0, content, (size_t)Hc * Wc * 3 * px, &dc));
+  TRY(stage_in(c, 1, style, (size_t)Hs * Ws * 3 * px, &ds));
   TRY(ensure(c, c->stage[2], (size_t)Ho * Wo * 3));
   TRY(wct_stylize_batch_dev(c, (uint8_t*)dc, Hc, Wc, (uint8_t*)ds, Hs, Ws, 1, levels, n_levels, alpha, flags,
                             (uint8_t*)c->stage[2].p));

@@ -1554,7 +1554,11 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
 // Converged = the sweep saw no rotated pair above tol_max (the classical test: the matrix was already diagonal to
 // tol_max BEFORE the sweep), or -- tol_fn > 0 -- the residual measured after the sweep is below tol_fn: the matrix
 // function built from this state with the first-order completion is then accurate to O(tol_fn^2).
-__global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int nmat, float tol_max, float tol_fn, int buf, int segs = 0) {
+// lenient_from: from this many completed sweeps on, a matrix whose SIGNIFICANT pairs were all below tol_max in the sweep
+// is done as well (what jacobi_finalize_kernel accepts when the budget runs out): the noise-level pairs of a
+// rank-deficient matrix never settle, and without this such a matrix always burns the whole sweep budget.
+__global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int nmat, float tol_max, float tol_fn, int buf, int segs = 0,
+                                    int lenient_from = 1 << 30) {
   const int m = threadIdx.x;
   if (m >= nmat || st[m].done) return;
   st[m].sweeps += 1;
@@ -1567,6 +1571,7 @@ __global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int n
   const unsigned bits = st[m].offmax;                   // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
   if (bits >= 0x7f800000u || !(r2 < 3.0e38f)) st[m].done = 2;
   else if (__uint_as_float(bits) < tol_max || (tol_fn > 0.f && r2 < tol_fn * tol_fn)) st[m].done = 1;
+  else if (st[m].sweeps >= lenient_from && __uint_as_float(st[m].offsig) < tol_max) st[m].done = 1;
   if (st[m].done) { st[m].pad = buf; st[m].seg_stop = segs; }
   st[m].last_sig = st[m].offsig;
   st[m].floor = fmaxf(st[m].floor, JACOBI_SIG_FLOOR * __uint_as_float(st[m].dmax));
@@ -1760,7 +1765,7 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
     jacobi_enqueue_steps<M2>(grp, ngrp, C, half, nblk - 1);
     for (int g = 0; g < ngrp; ++g) {
       hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C);
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, 0);
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, 0, 0, max_sweeps - 3);
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
       for (int g = 0; g < ngrp; ++g) {
@@ -1942,7 +1947,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     }
     for (int g = 0; g < ngrp; ++g) {
       hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C);
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs);
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, max_sweeps - 3);
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
       for (int g = 0; g < ngrp; ++g) {

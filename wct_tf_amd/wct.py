@@ -99,10 +99,8 @@ class WCT(object):
                 content = center_crop_to(content, H, W)
         if swap5:
             self.sess.set_style_swap(ss_alpha, self.ss_patch_size, self.ss_stride)
-        if content.dtype != np.uint8:
-            content = np.uint8(np.clip(content, 0, 255))
-        if style.dtype != np.uint8:
-            style = np.uint8(np.clip(style, 0, 255))
+        # uint8 arrays take the fused /255 on the device; float arrays are divided by 255 WITHOUT rounding, as the
+        # reference's preprocess does (wct.py:60-64) -- Context.stylize hands them over as float32 images
         return self.sess.stylize(content, style, self.relu_targets, alpha=alpha, adain=adain,
                                  wct_mode=self.wct_mode, swap5=bool(swap5))
 
