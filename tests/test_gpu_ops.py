@@ -275,6 +275,47 @@ def test_wct_cutoff_straddle(ctx):
             _check_wct(ctx, feats[0], feats[1], 0.8, mode)
 
 
+def test_wct_cutoff_straddle_within_one_per_cent(ctx):
+    """two eigenvalues 1 % above and 1 % below the 1e-5 cut-off.  The first-order completion of the spectral
+    functions divides the solver's residual by that gap; it is clamped to its bound f_k / 2 (spectral_entry), so the
+    output must stay finite and equal the oracle for the reference's kept count -- or, if fp32 noise moves one of the
+    two across the line, for a neighbouring count."""
+    rng = np.random.default_rng(99)
+    c, h, w = 64, 40, 40
+    feats = []
+    for side in range(2):
+        x = _graded_features(rng, h * w, c, 3.0)
+        x[:, :-2] *= 0.3 / x[:, :-2].std()
+        # two channels of variance 1.01 v and 0.99 v, made exactly uncorrelated with the others and with each other
+        # (sample correlations of ~N^-1/2 would split the pair by several per cent)
+        base = x[:, :-2] - x[:, :-2].mean(0)
+        z = rng.standard_normal((h * w, 2))
+        z -= z.mean(0)
+        z -= base @ np.linalg.lstsq(base, z, rcond=None)[0]
+        q, _ = np.linalg.qr(z)
+        x[:, -2] = q[:, 0] * 1e-3 * np.sqrt(1.01 * (h * w - 1))
+        x[:, -1] = q[:, 1] * 1e-3 * np.sqrt(0.99 * (h * w - 1))
+        ev = np.sort(np.linalg.eigvalsh(np.cov(np.float32(x).astype(np.float64).T)))
+        lo, hi = ev[0], ev[1]                                      # the pair: far below every other eigenvalue
+        assert hi / lo < 1.06 and ev[2] > 20 * hi, (lo, hi, ev[2])
+        x = np.float32(x * np.sqrt(1e-5 / np.sqrt(lo * hi)))
+        ev = np.sort(np.linalg.eigvalsh(np.cov(x.astype(np.float64).T)))
+        print('  side %d: pair at %.4e / %.4e, next %.2e, largest %.2e' % (side, ev[0], ev[1], ev[2], ev[-1]))
+        assert ev[0] < 1e-5 < ev[1] and ev[1] / ev[0] < 1.06
+        feats.append(x.reshape(1, h, w, c))
+    for mode in ('np', 'tf'):
+        fn = oracle.wct_np if mode == 'np' else oracle.wct_tf
+        got, sweeps = ctx.transform(feats[0].reshape(-1, c), feats[1].reshape(-1, c), 0.8,
+                                    _lib.WCT_NP if mode == 'np' else _lib.WCT_TF, return_sweeps=True)
+        assert np.all(np.isfinite(got))
+        errs = {(kc, ks): rel_err(got.reshape(1, h, w, c), fn(feats[0], feats[1], 0.8, keep=(kc, ks)))
+                for kc in (c - 2, c - 1, c) for ks in (c - 2, c - 1, c)}
+        best = min(errs, key=errs.get)
+        print('  mode %s sweeps %s: best kept counts %s rel %.2e (reference count %d/%d: %.2e)' % (mode, sweeps, best, errs[best], c - 1, c - 1, errs[(c - 1, c - 1)]))
+        assert errs[best] < WCT_TOL, (mode, errs)
+        assert np.abs(got).max() < 10 * np.abs(fn(feats[0], feats[1], 0.8)).max()
+
+
 def test_wct_ops_module_surface(ctx):
     from wct_tf_amd import ops
     fc = synthetic_features(61, 64, 12, 12, 2.0)

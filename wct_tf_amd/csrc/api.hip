@@ -217,6 +217,21 @@ static int eig_status(wct_ctx* c) {
   return WCT_ERR_NOCONV;
 }
 
+// At the START of a blocking call: failures still pending in the status words were raised by EARLIER asynchronous work
+// (wct_stylize_batch_dev calls that nobody followed with wct_sync).  They are reported now -- loudly, but named for what
+// they are, and before this call runs, so that its own status and sweep counts are never mixed with them.
+static int eig_stale(wct_ctx* c) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int n_open = 0, n_nan = 0;
+  for (int g = 0; g < 4; ++g) { n_open += c->eig_fail[2 * g]; n_nan += c->eig_fail[2 * g + 1]; }
+  if (!n_open && !n_nan) return WCT_OK;
+  for (int i = 0; i < 8; ++i) c->eig_fail[i] = 0;
+  wct_set_error("eigensolver failures of an EARLIER asynchronous wct_stylize_batch_dev call that was not followed by wct_sync "
+                "(%d matri%s still rotating after the sweep budget, %d with non-finite entries): the frames of that call are "
+                "not reliable; the present call was not started", n_open, n_open == 1 ? "x" : "ces", n_nan);
+  return WCT_ERR_NOCONV;
+}
+
 extern "C" int wct_sync(wct_ctx* c) {
   ARG_CHECK(c != nullptr);
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -610,6 +625,7 @@ extern "C" int wct_transform(wct_ctx* c, const float* content, int Nc, const flo
                              float alpha, int mode, float eps, float* out, int* sweeps_out) {
   ARG_CHECK(c && content && style && out && (mode == WCT_NP || mode == WCT_TF));
   HIP_TRY(hipSetDevice(c->device));
+  TRY(eig_stale(c));
   void *dc, *ds;
   TRY(stage_in(c, 0, content, (size_t)Nc * C * 4, &dc));
   TRY(stage_in(c, 1, style, (size_t)Ns * C * 4, &ds));
@@ -646,6 +662,7 @@ extern "C" int wct_style_swap(wct_ctx* c, const float* content, int hc, int wc, 
                               int C, float alpha, int patch_size, int stride, float eps, float* out) {
   ARG_CHECK(c && content && style && out && hc > 0 && wc > 0 && hs > 0 && ws > 0);
   HIP_TRY(hipSetDevice(c->device));
+  TRY(eig_stale(c));
   void *dc, *ds;
   TRY(stage_in(c, 0, content, (size_t)hc * wc * C * 4, &dc));
   TRY(stage_in(c, 1, style, (size_t)hs * ws * C * 4, &ds));
@@ -666,6 +683,7 @@ __global__ void extract_diag_kernel(const float* A, float* d, int C) {
 extern "C" int wct_eigh(wct_ctx* c, const float* A, int C, int nmat, float* evals, float* evecs, int* sweeps_out) {
   ARG_CHECK(c && A && evals && evecs && nmat >= 1 && nmat <= 64);
   HIP_TRY(hipSetDevice(c->device));
+  TRY(eig_stale(c));
   const size_t mb = (size_t)nmat * C * C * 4;
   void* dA;
   TRY(stage_in(c, 0, A, mb, &dA));
@@ -889,6 +907,7 @@ extern "C" int wct_stylize(wct_ctx* c, const uint8_t* content, int Hc, int Wc, c
                            const int* levels, int n_levels, float alpha, unsigned flags, uint8_t* out) {
   ARG_CHECK(c && content && style && out);
   HIP_TRY(hipSetDevice(c->device));
+  TRY(eig_stale(c));
   int Ho, Wo;
   TRY(wct_output_size(Hc, Wc, levels, n_levels, &Ho, &Wo));
   void *dc, *ds;

@@ -2040,7 +2040,10 @@ __device__ __forceinline__ float spectral_entry(float dp, float dq, float e, boo
   }
   const float dk = kp ? dp : dq, dd = kp ? dq : dp;
   const float fk = kind == 0 ? 1.f / sqrtf(dk + shift) : sqrtf(dk + shift);
-  return e * fk / (dk - dd);
+  // across the cut-off f jumps, and the first-order term e f_k / (d_k - d_d) is only the expansion of
+  // (f_k - 0) sin(theta) cos(theta) for a small rotation angle theta ~ e / gap: it can never exceed f_k / 2.  A residual
+  // that is not small against the gap (two eigenvalues within a per cent of 1e-5) is clamped to that bound
+  return e * fk / fmaxf(dk - dd, 2.f * fabsf(e));
 }
 
 __global__ void spectral_matrix_kernel(const float* A, float* G, int C, size_t stride, int kind, float shift, int correct) {

@@ -290,7 +290,17 @@ def train(argv=None):
         except StepFailed as e:                    # train.py:168-174: reload the latest checkpoint and go on -- all ranks together
             print(e)
             print('Exception encountered, re-loading latest checkpoint')
-            restored, step_saved = load_latest(args.checkpoint, relu)
+            # rank 0 owns the checkpoint directory (only it writes there): it loads, every rank receives the same
+            # weights and step -- on a filesystem that is not shared the ranks would otherwise restore different (or no)
+            # files and diverge silently
+            if dist is None or rank == 0:
+                restored, step_saved = load_latest(args.checkpoint, relu)
+            else:
+                restored, step_saved = None, None
+            if dist is not None:
+                box = [restored, step_saved]
+                dist.broadcast_object_list(box, src=0)
+                restored, step_saved = box
             if restored is None:
                 raise
             ctx.set_decoder(relu, restored)        # zero moments: the bias correction restarts with them
@@ -301,8 +311,11 @@ def train(argv=None):
             continue
         rec = dict(results, step=step, lr=lr, time=time.time() - start)
         if iteration % args.summary_iter == 0:          # a validation batch, evaluated without an update
-            val = one_step(val_q.get(), max(opt_step, 1), 0.0)
-            rec['val_total_loss'] = val['total_loss']
+            try:
+                val = one_step(val_q.get(), max(opt_step, 1), 0.0)
+                rec['val_total_loss'] = val['total_loss']
+            except StepFailed as e:                    # evaluation only: nothing to undo, every rank skips it together
+                print('validation batch skipped:', e)
         if rank == 0:
             log.write(json.dumps(rec) + '\n')
             log.flush()
