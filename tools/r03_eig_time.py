@@ -10,7 +10,7 @@ def spd(rng, c, n):
     return (x.T @ x / (n - 1)).astype(np.float32)
 ctx = Context(0)
 rng = np.random.default_rng(0)
-cases = [(512, 64), (512, 16), (512, 2), (256, 64)]
+cases = [(512, 64), (512, 16), (512, 2), (256, 64)] if len(sys.argv) < 2 else [(512, int(sys.argv[1]))]
 for c, nmat in cases:
     mats = np.stack([spd(rng, c, 4 * c) for _ in range(nmat)])
     def run():

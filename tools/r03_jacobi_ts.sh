@@ -7,5 +7,5 @@ cd wct_tf_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libwct_hip.so api.o conv.o /tmp/wct_ts.o coral.o train.o
 cd ../..
 cp wct_tf_amd/libwct_hip.so.src.sha256 /tmp/stamp.keep
-WCT_JACOBI_MAX_SWEEPS=4 WCT_JACOBI_MID=-1 timeout 200 python tools/r03_eig_time.py 2>&1 | grep -E "jacobi_ts|C="
+WCT_JACOBI_MAX_SWEEPS=4 WCT_JACOBI_MID=-1 timeout 200 python tools/r03_eig_time.py $1 2>&1 | grep -E "jacobi_ts|C="
 cp /tmp/libwct_hip.so.keep wct_tf_amd/libwct_hip.so

@@ -272,10 +272,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s) {
   g.nsplit = nsplit;
   const int gz = nsplit * nbatch;
-  if (g.M >= 128 && g.N >= 128) {
+  // few large tiles leave most of the chip idle when the batch is small (one pair's 512 x 512 products are 16 tiles of
+  // 128 x 128 with a K loop of 512: 45 us apiece, 0.9 ms of a batch-1 frame); 64 x 64 tiles give four times the blocks.
+  // Every output element is the same k-ordered fma chain under either tiling: the results are bit-identical.
+  const bool small_grid = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * gz < 256;
+  if (g.M >= 128 && g.N >= 128 && !small_grid) {
     dim3 grid(cdiv(g.N, 128), cdiv(g.M, 128), gz);
     hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, s, g);
-  } else if (g.M >= 128) {
+  } else if (g.M >= 128 && !small_grid) {
     dim3 grid(cdiv(g.N, 64), cdiv(g.M, 128), gz);
     hipLaunchKernelGGL((gemm_f32_kernel<128, 64>), grid, dim3(256), 0, s, g);
   } else {
@@ -524,6 +528,38 @@ constexpr float JACOBI_FLOOR = 1e-6f;      // both diagonals below this: the pai
 // `sig` = the same measure if the pair is significant (its larger diagonal is above the matrix' noise floor), else 0:
 // pairs inside the numerical null space keep relative off-diagonals of O(1) for ever (every update regenerates
 // rounding noise there) without mattering for f(A); they are still rotated, but they do not count as "not converged".
+// The same in two parts for the pivot wave of jacobi_cross_sets_pw: the rotation itself is on the serial chain of a set
+// (it gates every other wave at the barrier), the convergence statistics are not -- they are evaluated after (c, s) has
+// been published, under the latency of that LDS write.
+__device__ __forceinline__ bool jacobi_rotation_cs(float app, float aqq, float apq, float& c, float& s) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
+  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
+  const float tau = 0.5f * (aqq - app);
+  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
+  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
+  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
+  const float n2 = 1.f + t * t;
+  float r = __builtin_amdgcn_rsqf(n2);
+  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
+  c = rot ? r : 1.f;
+  s = rot ? r * t : 0.f;
+  return rot;
+}
+__device__ __forceinline__ void jacobi_rotation_stats(float app, float aqq, float apq, float floor_m, bool rot, float& off, float& sig) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  const float rel = den2 > 0.f ? fminf(aapq * __builtin_amdgcn_rsqf(den2), 1.f) : 1.f;
+  off = rot ? rel : 0.f;
+  // branch-free (selects, not exec-mask branches: the pivot wave is the pole of every set)
+  const float mixed = fmaxf(aapq * __builtin_amdgcn_rcpf(big), small < 1e-5f ? 0.1f * aapq * __builtin_amdgcn_rsqf(big * 1e-5f) : 0.f);
+  const float sig_mixed = big > floor_m ? fminf(off, mixed) : 0.f;
+  sig = small > floor_m ? off : sig_mixed;
+}
+
 __device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq, float floor_m, float& c, float& s, float& off, float& sig) {
   const float den2 = fabsf(app * aqq);
   const float aapq = fabsf(apq);
@@ -726,7 +762,7 @@ __device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned cha
 //     updated in place (one image instead of two); with PITCH = N the 8-byte accesses of a diagonal are conflict-free.
 // Per set a bulk wave issues ~45 instructions instead of ~100, and the dependent chain of a set is the pivot wave's.
 template <int N>
-__device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned char* csb, int t, float floor_m, float& my_off, float& my_sig) {
+__device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned char* csb, int t, float floor_m, float& my_off, float& my_sig, int exp_mode = 0) {
   constexpr int NP = N / 2, ROWB = N * 8;                            // bytes per image row
   constexpr int CSB = NP * 8, DUMMY = 2 * CSB;                       // csb layout: CS[2][NP] float2 (c, s), dummy float2
   const int k = t & (NP - 1), d = t / NP;
@@ -759,33 +795,43 @@ __device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned
     const int a_pq = row_pk + qlb, a_qp = qkb + col_pl, a_qq = qkb + qlb;
     const f32x2 app = ld2(sq, a_pp), apq = ld2(sq, a_pq), aqp = ld2(sq, a_qp), aqq = ld2(sq, a_qq);
     const float cl = rl[0], sl = rl[1], ckk = rk[0], skk = rk[1];
-    // columns (pair l) on S and Q, then rows (pair k) on S
-    const float ypp = cl * app[0] - sl * apq[0], ypq = sl * app[0] + cl * apq[0];
-    const float yqp = cl * aqp[0] - sl * aqq[0], yqq = sl * aqp[0] + cl * aqq[0];
-    f32x2 npp, npq, nqp, nqq;
-    npp[1] = cl * app[1] - sl * apq[1];  npq[1] = sl * app[1] + cl * apq[1];
-    nqp[1] = cl * aqp[1] - sl * aqq[1];  nqq[1] = sl * aqp[1] + cl * aqq[1];
-    npp[0] = ckk * ypp - skk * yqp;  npq[0] = ckk * ypq - skk * yqq;
-    nqp[0] = skk * ypp + ckk * yqp;  nqq[0] = skk * ypq + ckk * yqq;
+    // columns (pair l) on the {S, Q} pairs as packed operations -- the same (c_l, s_l) acts on both halves of a
+    // float2, so v_pk_mul / v_pk_fma take the scalars broadcast and need no operand assembly --, then rows (pair k) on
+    // the S halves alone.  (Written element by element the same arithmetic came out of hipcc as 12 packed operations
+    // fed by ~30 v_mov: the set loop is VALU-issue bound, ablation in profiles/r03_jacobi_set_ablation.txt.)
+    const f32x2 ypp = cl * app - sl * apq, ypq = sl * app + cl * apq;
+    const f32x2 yqp = cl * aqp - sl * aqq, yqq = sl * aqp + cl * aqq;
+    f32x2 npp = ypp, npq = ypq, nqp = yqp, nqq = yqq;
+    npp[0] = ckk * ypp[0] - skk * yqp[0];  npq[0] = ckk * ypq[0] - skk * yqq[0];
+    nqp[0] = skk * ypp[0] + ckk * yqp[0];  nqq[0] = skk * ypq[0] + ckk * yqq[0];
     if (pwave) {
       // pair k after this set's rotation (closed form from registers), the next set's partner diagonal from the
-      // lane of pair k+1, the next pivot element from this thread's own block
+      // lane of pair k+1 -- a DPP wave shift (lane i reads lane i+1), the wrap-around lane NP-1 <- 0 patched with a
+      // v_readlane: no LDS round trip on the chain (round 2 used ds_bpermute here) --, the next pivot element from
+      // this thread's own block
       const float c2 = ck * ck, s2 = sk * sk, cs2 = 2.f * ck * sk;
       const float ppn = c2 * ppk - cs2 * pqk + s2 * qqk;
       const float qqn = s2 * ppk + cs2 * pqk + c2 * qqk;
-      const float qq_next = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb_lane * 4, __builtin_bit_cast(int, qqn)));
+      const int qqn_i = __builtin_bit_cast(int, qqn);
+      const int shl = __builtin_amdgcn_update_dpp(qqn_i, qqn_i, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+      const int first = __builtin_amdgcn_readlane(qqn_i, 0);
+      const float qq_next = __builtin_bit_cast(float, k == NP - 1 ? first : shl);
       ppk = ppn; qqk = qq_next; pqk = npq[0];
-      float off, sig;
-      jacobi_rotation(ppk, qqk, pqk, floor_m, ck, sk, off, sig);
-      if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
+      bool rot = false;
+      if (!(exp_mode & 16)) rot = jacobi_rotation_cs(ppk, qqk, pqk, ck, sk);     // (timing experiment: no rotation on the chain)
       f32x2 r; r[0] = ck; r[1] = sk;
       *reinterpret_cast<f32x2*>(csb + (NX ? cs_w1 : cs_w0)) = r;
+      float off, sig;
+      jacobi_rotation_stats(ppk, qqk, pqk, floor_m, rot, off, sig);
+      if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
     }
+    if (!(exp_mode & 64)) {                                          // (timing experiment: no image stores)
     *reinterpret_cast<f32x2*>(sq + a_pp) = npp;  *reinterpret_cast<f32x2*>(sq + a_pq) = npq;
     *reinterpret_cast<f32x2*>(sq + a_qp) = nqp;  *reinterpret_cast<f32x2*>(sq + a_qq) = nqq;
+    } else { my_off += npp[0] + npq[1] + nqp[0] + nqq[1]; }
     qk = NP | ((qk + 1) & (NP - 1));
     ql = NP | ((ql + 1) & (NP - 1));
-    __syncthreads();
+    if (!(exp_mode & 32)) __syncthreads();                           // (timing experiment: no barrier per set)
   };
 #pragma unroll 1
   for (int s = 0; s < NP; s += 2) {
@@ -1190,7 +1236,7 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
   }
   JTS(4);
   if (p.step_d >= 0) {
-    if (!(p.dbg & 4)) jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig);
+    if (!(p.dbg & 4)) jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig, p.dbg);
     JTS(5);
     for (int e = tid; e < M2 * M2; e += NT) So[e] = SQ[e][0];
     int qr, qc;
@@ -1356,6 +1402,7 @@ struct VStripArgs {
   float* V; const float* Qlog;      // Qlog: [slot][nmat][npair][M2*M2] fragment order, slot = step - step_begin
   const JacobiState* st;
   int C, nmat, step_begin, step_end, seg;
+  int dbg;       // timing experiment (WCT_JACOBI_DBG & 128): return at once
 };
 
 template <int M2, int NBLK, int W>
@@ -1364,7 +1411,7 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
   constexpr int NLD = FR / 4 / (W * 64) > 0 ? FR / 4 / (W * 64) : 1;        // float4 per thread and tile
   __shared__ __attribute__((aligned(16))) float qs[2][FR];
   const int m = blockIdx.y;
-  if (p.st[m].seg_stop <= p.seg) return;        // no rotations of this segment belong to the matrix (done before it began)
+  if (p.st[m].seg_stop <= p.seg || p.dbg) return;   // no rotations of this segment belong to the matrix (done before it began)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int row0 = (blockIdx.x * W + wave) * 16;
@@ -1851,6 +1898,8 @@ static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_
   const int nblk = C / (M2 / 2);
   VStripArgs a;
   a.V = G.V; a.Qlog = G.Qlog[G.lg]; a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_begin = step_begin; a.step_end = step_end; a.seg = G.segs;
+  static const int dbg = getenv("WCT_JACOBI_DBG") ? atoi(getenv("WCT_JACOBI_DBG")) : 0;
+  a.dbg = dbg & 128;
 #define VSTRIP_CASE(m2, nb, w) \
   if (M2 == m2 && nblk == nb) hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), dim3(C / 16 / w, G.nmat), dim3(w * 64), 0, s, a);
   VSTRIP_CASE(64, 16, 4) VSTRIP_CASE(64, 8, 8) VSTRIP_CASE(32, 8, 4) VSTRIP_CASE(32, 4, 4) VSTRIP_CASE(32, 2, 2)
