@@ -1068,6 +1068,7 @@ struct JacobiFusedArgs {
   float* V;             // [nmat][C][C] eigenvector accumulation, in place
   const float* Qr; const float* Sr;   // [nmat][npair][M2*M2] rotations / rotated pair problems of step_u
   float* Qw; float* Sw;               // ... written by the D part (step_d)
+  const half_t* Qr16; half_t* Qw16;   // the same rotations split into fp16 hi + lo MFMA fragments (V <- V Q; see qfrag16)
   JacobiState* st;
   int C, nmat;
   int step_d, step_u;   // outer step of the pair problems / of the tile update (= the step before step_d)
@@ -1098,6 +1099,25 @@ __device__ __forceinline__ void block_locate(int b, int step, int nblk, int& g, 
   }
   const int npair = nblk >> 1;
   if (pos < npair) { g = pos; half = 0; } else { g = nblk - 1 - pos; half = 1; }
+}
+
+// V <- V Q runs on the fp16 MFMA pipe with split operands (hi = fp16(x), lo = fp16(x - hi): 22 significand bits; hi*hi +
+// hi*lo + lo*hi accumulated in fp32 -- the covariance kernel's scheme): the entries of V and Q are bounded by 1, and three
+// v_mfma_f32_16x16x32_f16 replace eight v_mfma_f32_16x16x4_f32 at a sixteenth of their cost each.  The rotation matrices
+// are therefore ALSO stored as fp16 fragments: unit u = ((mt * NCH + c) * 2 + part) * 64 + lane (16 bytes = 8 halfs;
+// part 0 = hi, 1 = lo; NCH = M2 / 32 K-chunks) holds the A operand of output tile mt and chunk c for lane (m, g) = (lane
+// & 15, lane >> 4): element j is Q[k][16 mt + m] with k = 16 (2 c + (j >> 2)) + 4 g + (j & 3).  That k-slot order is
+// what makes the accumulator layout of a 16 x 16 tile of V^T (lane (n, g), register r <-> V[n][4 g + r]) the B operand
+// of the next product without any data movement: elements 0..3 come from tile 2c, 4..7 from tile 2c + 1.
+template <int M2>
+__device__ __forceinline__ int qfrag16_k(int c, int g, int j) { return 16 * (2 * c + (j >> 2)) + 4 * g + (j & 3); }
+
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (half_t)x[j];
+    lo[j] = (half_t)(x[j] - (float)hi[j]);
+  }
 }
 
 template <int M2>
@@ -1245,6 +1265,16 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) q[j] = SQ[(qr + j) * M2 + qc][1];
     *reinterpret_cast<f32x4*>(Qo + (size_t)tid * 4) = q;
+    {  // fp16 hi / lo fragment unit `tid`
+      constexpr int NCH = M2 / 32;
+      const int l16 = tid & 63, part = (tid >> 6) & 1, cc = (tid >> 7) % NCH, mt = (tid >> 7) / NCH;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = SQ[qfrag16_k<M2>(cc, l16 >> 4, j) * M2 + 16 * mt + (l16 & 15)][1];
+      half8 hi, lo;
+      split_f16x8(x, hi, lo);
+      *reinterpret_cast<half8*>(p.Qw16 + ((size_t)m * npair + g) * (2 * M2 * M2) + (size_t)tid * 8) = part ? lo : hi;
+    }
   } else {
     constexpr int PITCH = M2 + 1;
     float* DO = jsm + 4 * M2 * PITCH;
@@ -1257,6 +1287,16 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) q[j] = SQ[cur * M2 * PITCH + (qr + j) * PITCH + qc][1];
     *reinterpret_cast<f32x4*>(Qo + (size_t)tid * 4) = q;
+    {
+      constexpr int NCH = M2 / 32;
+      const int l16 = tid & 63, part = (tid >> 6) & 1, cc = (tid >> 7) % NCH, mt = (tid >> 7) / NCH;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = SQ[cur * M2 * PITCH + qfrag16_k<M2>(cc, l16 >> 4, j) * PITCH + 16 * mt + (l16 & 15)][1];
+      half8 hi, lo;
+      split_f16x8(x, hi, lo);
+      *reinterpret_cast<half8*>(p.Qw16 + ((size_t)m * npair + g) * (2 * M2 * M2) + (size_t)tid * 8) = part ? lo : hi;
+    }
   }
   if (!finite) my_off = __builtin_inff();
   for (int o = 32; o > 0; o >>= 1) {
@@ -1323,15 +1363,23 @@ __device__ __forceinline__ void jacobi_fused_u(const JacobiFusedArgs& p, int m, 
   const int ti = wave / NW, tj = wave % NW, li = lane & 15, lq = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (is_v) {
-    // V Qh with the k-slots of jacobi_vstrip_kernel (MFMA (t, r) covers k = 16 t + 4 q + r, q = 0..3): an MFMA is a
-    // k-ordered fma chain per output element, so V comes out bit-identical whichever kernel updates it
+    // (V Qh)^T = Qh^T V^T tile (column tile tj, rows 16 ti ..) exactly as jacobi_vstrip_kernel computes it -- the same
+    // split-fp16 operands, k-slots and order of the MFMAs -- so V comes out bit-identical whichever kernel updates it
+    constexpr int NCH = M2 / 32;
+    const half_t* q16 = p.Qr16 + ((size_t)m * npair + h) * (2 * M2 * M2);
 #pragma unroll
-    for (int t = 0; t < NW; ++t)
+    for (int c = 0; c < NCH; ++c) {
+      float x[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 16 * t + 4 * lq + r;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[(16 * ti + li) * PITCH + k], Qhs[k * PITCH + 16 * tj + li], acc, 0, 0, 0);
-      }
+      for (int j = 0; j < 8; ++j) x[j] = Xs[(16 * ti + li) * PITCH + qfrag16_k<M2>(c, lq, j)];
+      half8 bh, bl;
+      split_f16x8(x, bh, bl);
+      const half8 ah = *reinterpret_cast<const half8*>(q16 + ((size_t)((tj * NCH + c) * 2 + 0) * 64 + lane) * 8);
+      const half8 al = *reinterpret_cast<const half8*>(q16 + ((size_t)((tj * NCH + c) * 2 + 1) * 64 + lane) * 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+    }
   } else {
 #pragma unroll 4
     for (int kk = 0; kk < M2; kk += 4)      // T = X Qh
@@ -1353,10 +1401,9 @@ __device__ __forceinline__ void jacobi_fused_u(const JacobiFusedArgs& p, int m, 
     // mirror tile (h, g): this lane's four rows are four consecutive columns there
     *reinterpret_cast<f32x4*>(Pw + (size_t)col * C + pair_index<B>(16 * ti + 4 * lq, gi, gj)) = acc;
   } else {
+    // lane (n, q), register r = (V Qh)[row 16 ti + n][column 16 tj + 4 q + r]: four consecutive columns
     float* Vm = p.V + m * cc;
-    const int col = pair_index<B>(16 * tj + li, hi, hj);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Vm[(size_t)(g * M2 + 16 * ti + 4 * lq + r) * C + col] = acc[r];
+    *reinterpret_cast<f32x4*>(Vm + (size_t)(g * M2 + 16 * ti + li) * C + pair_index<B>(16 * tj + 4 * lq, hi, hj)) = acc;
   }
 }
 
@@ -1399,7 +1446,7 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_
 // the next segment's pair problems (MFMA pipe and registers here, LDS and VALU there).
 // ---------------------------------------------------------------------------
 struct VStripArgs {
-  float* V; const float* Qlog;      // Qlog: [slot][nmat][npair][M2*M2] fragment order, slot = step - step_begin
+  float* V; const half_t* Qlog;     // Qlog: [slot][nmat][npair][2*M2*M2] fp16 hi/lo fragments (qfrag16), slot = step - step_begin
   const JacobiState* st;
   int C, nmat, step_begin, step_end, seg;
   int dbg;       // timing experiment (WCT_JACOBI_DBG & 128): return at once
@@ -1407,7 +1454,7 @@ struct VStripArgs {
 
 template <int M2, int NBLK, int W>
 __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
-  constexpr int B = M2 / 2, TB = B / 16, NTL = M2 / 16, NPAIR = NBLK / 2, FR = M2 * M2, C = NBLK * B;
+  constexpr int B = M2 / 2, TB = B / 16, NCH = M2 / 32, NPAIR = NBLK / 2, FR = M2 * M2, C = NBLK * B;
   constexpr int NLD = FR / 4 / (W * 64) > 0 ? FR / 4 / (W * 64) : 1;        // float4 per thread and tile
   __shared__ __attribute__((aligned(16))) float qs[2][FR];
   const int m = blockIdx.y;
@@ -1425,59 +1472,84 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
     for (int tb = 0; tb < TB; ++tb) v[pos * TB + tb] = *reinterpret_cast<const f32x4*>(Vm + blk * B + tb * 16);
   }
   const size_t slot_stride = (size_t)p.nmat * NPAIR * FR;
-  const float* qbase = p.Qlog + (size_t)m * NPAIR * FR;
+  const float* qbase = reinterpret_cast<const float*>(p.Qlog) + (size_t)m * NPAIR * FR;   // a tile of fp16 hi/lo fragments = FR * 4 bytes too
   // tile q of the segment: step = step_begin + q / NPAIR, pair = q % NPAIR
   const int ntile = (p.step_end - p.step_begin) * NPAIR;
-  f32x4 pre[NLD];
-  auto fetch = [&](int q) {
+  // The rotation log streams from HBM (128 MB per segment at 64 matrices): ~2 us per access.  A tile is requested
+  // PD pairs before it is used (PD register sets, one per pair of a step where the step has that many), parked in LDS
+  // one pair ahead; with a single tile in flight the kernel ran at one memory latency per pair (260 us per launch).
+  constexpr int PD = NPAIR < 4 ? NPAIR : 4;
+  f32x4 pre[PD][NLD];
+  auto fetch = [&](int q, auto SET) {
+    constexpr int set = decltype(SET)::value;
     const float* src = qbase + (size_t)(q / NPAIR) * slot_stride + (size_t)(q % NPAIR) * FR;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int f = tid + i * W * 64;
-      if (FR / 4 >= W * 64 || f < FR / 4) pre[i] = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
+      if (FR / 4 >= W * 64 || f < FR / 4) pre[set][i] = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
     }
   };
-  auto park = [&](int buf) {
+  auto park = [&](auto SET, int buf) {
+    constexpr int set = decltype(SET)::value;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int f = tid + i * W * 64;
-      if (FR / 4 >= W * 64 || f < FR / 4) *reinterpret_cast<f32x4*>(&qs[buf][f * 4]) = pre[i];
+      if (FR / 4 >= W * 64 || f < FR / 4) *reinterpret_cast<f32x4*>(&qs[buf][f * 4]) = pre[set][i];
     }
   };
-  fetch(0);
-  park(0);
+  {
+    // tiles 0 .. PD-1 of the segment into the register sets (a segment has at least NPAIR >= PD tiles)
+    auto prime = [&](auto I) { fetch(decltype(I)::value, I); };
+    prime(std::integral_constant<int, 0>{});
+    if constexpr (PD > 1) prime(std::integral_constant<int, 1>{});
+    if constexpr (PD > 2) { prime(std::integral_constant<int, 2>{}); prime(std::integral_constant<int, 3>{}); }
+    if constexpr (PD > 4) { prime(std::integral_constant<int, 4>{}); prime(std::integral_constant<int, 5>{}); prime(std::integral_constant<int, 6>{}); prime(std::integral_constant<int, 7>{}); }
+  }
+  park(std::integral_constant<int, 0>{}, 0);
   __syncthreads();
   int q = 0;
-  // one pair: tiles x[0..2TB) = positions pa, pb; out[mt] = sum_t sum_r mfma(Qf[mt][t][r], x[t][r]).  pa / pb are
-  // compile-time constants once the loops over g below are unrolled (the strip must stay in registers)
-#define VSTRIP_PAIR(pa, pb)                                                                                          \
+  // one pair (the g-th of its step: g is a compile-time constant once the loops below are unrolled, and so are the
+  // positions pa / pb and the register sets g % PD, (g + 1) % PD): tiles x = positions pa, pb;
+  // out[mt] = sum over chunks of the three split-operand MFMAs.  The strip must stay in registers.
+#define VSTRIP_PAIR(pa, pb, g)                                                                                       \
   {                                                                                                                  \
-    if (q + 1 < ntile) fetch(q + 1);                                                                                 \
-    const float* qb = qs[q & 1];                                                                                     \
+    if (q + PD < ntile) fetch(q + PD, std::integral_constant<int, (g) % PD>{});   /* the set tile q came from is free */ \
+    const half_t* qb = reinterpret_cast<const half_t*>(qs[q & 1]);                                                   \
     f32x4 out[2 * TB];                                                                                               \
     _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};                      \
-    _Pragma("unroll") for (int t = 0; t < 2 * TB; ++t) {                                                             \
-      const f32x4 x = t < TB ? v[(pa) * TB + t] : v[(pb) * TB + t - TB];                                             \
-      f32x4 a[2 * TB];                                                                                               \
-      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                          \
-        a[mt] = *reinterpret_cast<const f32x4*>(qb + ((mt * NTL + t) * 64 + lane) * 4);                              \
-      _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                                  \
-        _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                        \
-          out[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][r], x[r], out[mt], 0, 0, 0);                          \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                                \
+      /* tiles 2c, 2c+1 of the pair's 2 TB tiles: positions pa (tiles 0..TB-1) and pb (TB..2TB-1) */                 \
+      const f32x4 x0 = 2 * c < TB ? v[(pa) * TB + 2 * c] : v[(pb) * TB + 2 * c - TB];                                \
+      const f32x4 x1 = 2 * c + 1 < TB ? v[(pa) * TB + 2 * c + 1] : v[(pb) * TB + 2 * c + 1 - TB];                    \
+      const float xx[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};                                  \
+      half8 bh, bl;                                                                                                  \
+      split_f16x8(xx, bh, bl);                                                                                       \
+      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) {                                                        \
+        const half8 ah = *reinterpret_cast<const half8*>(qb + (((mt * NCH + c) * 2 + 0) * 64 + lane) * 8);           \
+        const half8 al = *reinterpret_cast<const half8*>(qb + (((mt * NCH + c) * 2 + 1) * 64 + lane) * 8);           \
+        out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, out[mt], 0, 0, 0);                                  \
+        out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, out[mt], 0, 0, 0);                                  \
+        out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, out[mt], 0, 0, 0);                                  \
+      }                                                                                                              \
     }                                                                                                                \
     _Pragma("unroll") for (int t = 0; t < TB; ++t) { v[(pa) * TB + t] = out[t]; v[(pb) * TB + t] = out[TB + t]; }    \
-    if (q + 1 < ntile) park((q + 1) & 1);                                                                            \
+    if (q + 1 < ntile) park(std::integral_constant<int, ((g) + 1) % PD>{}, (q + 1) & 1);                             \
     __syncthreads();                                                                                                 \
     ++q;                                                                                                             \
   }
+  // (the loops over g are spelled out with compile-time g: `#pragma unroll` alone leaves g a variable inside the macro)
+  auto step_pairs = [&](auto INTRA) {
+    constexpr bool intra = decltype(INTRA)::value;
+#define VP(G) if constexpr ((G) < NPAIR) { if constexpr (intra) VSTRIP_PAIR(2 * (G), 2 * (G) + 1, G) else VSTRIP_PAIR(G, NBLK - 1 - (G), G) }
+    VP(0) VP(1) VP(2) VP(3) VP(4) VP(5) VP(6) VP(7)
+#undef VP
+  };
 #pragma unroll 1
   for (int step = p.step_begin; step < p.step_end; ++step) {
     if (step < 0) {
-#pragma unroll
-      for (int g = 0; g < NPAIR; ++g) VSTRIP_PAIR(2 * g, 2 * g + 1)          // natural order
+      step_pairs(std::true_type{});          // natural order
     } else {
-#pragma unroll
-      for (int g = 0; g < NPAIR; ++g) VSTRIP_PAIR(g, NBLK - 1 - g)
+      step_pairs(std::false_type{});
       if (step + 1 < p.step_end && NBLK > 2) {        // positions of the next step: pos <- pos + 1, NBLK - 1 <- 1
         f32x4 keep[TB];
 #pragma unroll
@@ -1693,9 +1765,9 @@ static int jacobi_max_sweeps() {
 
 size_t jacobi_workspace_bytes(int C, int nmat) {
   // per matrix: the rotation log of two launch segments (2 x C/B steps x C/M2 tiles x M2^2 = 4 C^2 floats for both block
-  // widths), two generations of rotated pair problems (2 x C x M2 <= 128 C), the second matrix buffer (C^2); then state
+  // widths) and the same again as fp16 hi/lo fragments, two generations of rotated pair problems (2 x C x M2 <= 128 C), the second matrix buffer (C^2); then state
   // words and residual partials
-  return (size_t)nmat * ((size_t)5 * C * C + (size_t)128 * C) * sizeof(float) + 1024 +
+  return (size_t)nmat * ((size_t)9 * C * C + (size_t)128 * C) * sizeof(float) + 1024 +
          (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_CHUNKS * 4 * sizeof(float));
 }
 
@@ -1703,6 +1775,7 @@ size_t jacobi_workspace_bytes(int C, int nmat) {
 // that one half's latency-bound pair problems hide under the other half's chip-wide tile update).
 struct JacobiGroup {
   float* A; float* V; int nmat; float* Qbuf; JacobiState* st; float* resid; hipStream_t stream; int* sweeps_out;
+  half_t* Qlog16[2];                         // the same rotation logs as fp16 hi/lo fragments (V <- V Q)
   float* Qlog[2]; float* Sb[2]; float* P[2]; // look-ahead path: rotation logs of two segments, rotated pair problems of two
                                              // consecutive steps, the two matrix buffers (P[0] = A)
   int cur, par, lg, segs;                    // buffer holding the matrices; generation of the last pair problems; log in use;
@@ -1840,6 +1913,7 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
   JacobiFusedArgs a;
   a.Pr = G.P[G.cur]; a.Pw = G.P[G.cur ^ 1]; a.V = G.V;
   a.Qr = G.Qlog[G.lg] + (size_t)(step_u - seg_begin) * slot; a.Qw = G.Qlog[G.lg] + (size_t)(step_d - seg_begin) * slot;
+  a.Qr16 = G.Qlog16[G.lg] + (size_t)(step_u - seg_begin) * slot * 2; a.Qw16 = G.Qlog16[G.lg] + (size_t)(step_d - seg_begin) * slot * 2;
   a.Sr = G.Sb[G.par]; a.Sw = G.Sb[G.par ^ 1];
   a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_d = step_d; a.step_u = step_u;
   a.has_d = has_d; a.has_u = has_u; a.first = first; a.with_v = !G.vstrip;
@@ -1897,7 +1971,7 @@ template <int M2>
 static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_end, hipStream_t s) {
   const int nblk = C / (M2 / 2);
   VStripArgs a;
-  a.V = G.V; a.Qlog = G.Qlog[G.lg]; a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_begin = step_begin; a.step_end = step_end; a.seg = G.segs;
+  a.V = G.V; a.Qlog = G.Qlog16[G.lg]; a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_begin = step_begin; a.step_end = step_end; a.seg = G.segs;
   static const int dbg = getenv("WCT_JACOBI_DBG") ? atoi(getenv("WCT_JACOBI_DBG")) : 0;
   a.dbg = dbg & 128;
 #define VSTRIP_CASE(m2, nb, w) \
@@ -1952,7 +2026,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
   static const int mid_env = getenv("WCT_JACOBI_MID") ? atoi(getenv("WCT_JACOBI_MID")) : 3;
   // V in registers, per segment (jacobi_vstrip_kernel): 0 never, 1 from WCT_JACOBI_VSTRIP_MIN matrices per group on, 2 always
   static const int vs_env = getenv("WCT_JACOBI_VSTRIP") ? atoi(getenv("WCT_JACOBI_VSTRIP")) : 1;
-  static const int vs_min = getenv("WCT_JACOBI_VSTRIP_MIN") ? atoi(getenv("WCT_JACOBI_VSTRIP_MIN")) : 8;
+  static const int vs_min = getenv("WCT_JACOBI_VSTRIP_MIN") ? atoi(getenv("WCT_JACOBI_VSTRIP_MIN")) : 24;
   const int mid_from = nblk >= 8 ? mid_env : -1;
   JacobiHost* host = jacobi_host();
   for (int g = 0; g < ngrp; ++g) {
@@ -2023,11 +2097,12 @@ static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && nmat >= 1 && nmat <= 64);
   ARG_CHECK(workspace_bytes >= jacobi_workspace_bytes(C, nmat));
   const size_t cc = (size_t)C * C;
-  const size_t qbytes = (size_t)nmat * (5 * cc + (size_t)128 * C) * sizeof(float);
+  const size_t qbytes = (size_t)nmat * (9 * cc + (size_t)128 * C) * sizeof(float);
   G->A = A; G->V = V; G->nmat = nmat; G->Qbuf = reinterpret_cast<float*>(workspace);
   G->Qlog[0] = G->Qbuf; G->Qlog[1] = G->Qbuf + 2 * cc * nmat;
   G->Sb[0] = G->Qbuf + 4 * cc * nmat; G->Sb[1] = G->Sb[0] + (size_t)64 * C * nmat;
   G->P[0] = A; G->P[1] = G->Sb[1] + (size_t)64 * C * nmat; G->cur = 0; G->par = 0; G->lg = 0; G->segs = 0;
+  G->Qlog16[0] = reinterpret_cast<half_t*>(G->P[1] + cc * nmat); G->Qlog16[1] = G->Qlog16[0] + 4 * cc * nmat;
   G->vstrip = 0; G->vs = nullptr; G->v_busy[0] = G->v_busy[1] = false;
   G->st = reinterpret_cast<JacobiState*>(reinterpret_cast<char*>(workspace) + ((qbytes + 255) / 256) * 256);
   G->resid = reinterpret_cast<float*>(reinterpret_cast<char*>(G->st) + (((size_t)nmat * sizeof(JacobiState) + 255) / 256) * 256);
