@@ -1143,13 +1143,17 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
   f32x2* SQ = reinterpret_cast<f32x2*>(jsm);
   int bi, bj;
   block_pair(g, p.step_d, nblk, bi, bj);
-  const float floor_m = p.st[m].floor;
-  JTS(1);
+  // the matrix' state words (done, floor) are read AFTER the block's data loads have been issued: a done matrix costs a few
+  // wasted loads, a live one no longer waits a memory round trip before it requests anything (round 3 phase stamps)
+  float floor_m = 0.f;
   float my_off = 0.f, my_sig = 0.f, my_dm = 0.f;
   bool finite = true;
   float* Qo = p.Qw + ((size_t)m * npair + g) * (M2 * M2);
   float* So = p.Sw + ((size_t)m * npair + g) * (M2 * M2);
   if (p.first) {
+    if (p.st[m].done || (p.dbg & 2)) return;
+    floor_m = p.st[m].floor;
+    JTS(1);
     const float* Am = p.Pr + (size_t)m * C * C;
     const int PITCH = p.step_d >= 0 ? M2 : M2 + 1;
     for (int e = tid; e < M2 * M2; e += NT) {
@@ -1181,32 +1185,37 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
       const int cc = (clo ? h1 : h2) * B + (clo ? c : c - B);
       sv[i] = (rlo == clo || same) ? src[rr * M2 + cc] : 0.f;
     }
-    f32x4 crit = {0.f, 0.f, 0.f, 0.f};
+    float* Xs = jsm;                                // [M2][M2 + 1]  tile (g1, g2) of the state before U(step_u)
+    float* Q1s = Xs + M2 * (M2 + 1);                // [M2][B + 1]   columns h1 of Q_g1
+    float* Q2s = Q1s + M2 * (B + 1);                // [M2][B + 1]   columns h2 of Q_g2
+    float* Ws = Q2s + M2 * (B + 1);                 // [B][M2 + 1]   Q_g1[:, h1]^T X
+    f32x4 xv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+    const int se = tid * 4, sr = se / M2, sc = se % M2;
+    float* Qdst = nullptr;
     if (!same) {
-      float* Xs = jsm;                              // [M2][M2 + 1]  tile (g1, g2) of the state before U(step_u)
-      float* Q1s = Xs + M2 * (M2 + 1);              // [M2][B + 1]   columns h1 of Q_g1
-      float* Q2s = Q1s + M2 * (B + 1);              // [M2][B + 1]   columns h2 of Q_g2
-      float* Ws = Q2s + M2 * (B + 1);               // [B][M2 + 1]   Q_g1[:, h1]^T X
       int b1i, b1j, b2i, b2j;
       block_pair(g1, p.step_u, nblk, b1i, b1j);
       block_pair(g2, p.step_u, nblk, b2i, b2j);
       const float* Pm = p.Pr + (size_t)m * C * C;
-      {
-        const int e = tid * 4, r = e / M2, c = e % M2;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(Pm + (size_t)pair_index<B>(r, b1i, b1j) * C + pair_index<B>(c, b2i, b2j));
-        // Q columns: M2 x B floats per side = NT / 2 float4 (the fragments mt of that half); first half of the block
-        // fetches Q_g1, second half Q_g2
-        const bool one = tid < NT / 2;
-        const int t2 = one ? tid : tid - NT / 2;
-        const int f = (one ? h1 : h2) * (NT / 2) + t2;
-        int qr, qc;
-        qfrag_rc<M2>(f, qr, qc);
-        qc -= (one ? h1 : h2) * B;
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + (one ? g1 : g2)) * (M2 * M2) + (size_t)f * 4);
-        float* Qdst = (one ? Q1s : Q2s) + qr * (B + 1) + qc;
+      xv = *reinterpret_cast<const f32x4*>(Pm + (size_t)pair_index<B>(sr, b1i, b1j) * C + pair_index<B>(sc, b2i, b2j));
+      // Q columns: M2 x B floats per side = NT / 2 float4 (the fragments mt of that half); first half of the block
+      // fetches Q_g1, second half Q_g2
+      const bool one = tid < NT / 2;
+      const int t2 = one ? tid : tid - NT / 2;
+      const int f = (one ? h1 : h2) * (NT / 2) + t2;
+      int qr, qc;
+      qfrag_rc<M2>(f, qr, qc);
+      qc -= (one ? h1 : h2) * B;
+      qv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + (one ? g1 : g2)) * (M2 * M2) + (size_t)f * 4);
+      Qdst = (one ? Q1s : Q2s) + qr * (B + 1) + qc;
+    }
+    if (p.st[m].done || (p.dbg & 2)) return;        // (block-uniform)
+    floor_m = p.st[m].floor;
+    JTS(1);
+    f32x4 crit = {0.f, 0.f, 0.f, 0.f};
+    if (!same) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { Xs[r * (M2 + 1) + c + j] = xv[j]; Qdst[j * (B + 1)] = qv[j]; }
-      }
+      for (int j = 0; j < 4; ++j) { Xs[sr * (M2 + 1) + sc + j] = xv[j]; Qdst[j * (B + 1)] = qv[j]; }
       __syncthreads();
       JTS(2);
       const int li = lane & 15, lq = lane >> 4;
@@ -1235,6 +1244,8 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
       if ((r < B) == (c < B) || same) {
         f32x2 v; v[0] = sv[i]; v[1] = r == c ? 1.f : 0.f;
         SQ[e] = v;
+        finite &= fabsf(sv[i]) <= 3.0e38f;
+        if (r == c) my_dm = fmaxf(my_dm, fabsf(sv[i]));
       }
     }
     if (!same && wave < (B / 16) * (B / 16)) {
@@ -1245,14 +1256,10 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
         f32x2 v; v[0] = crit[r]; v[1] = 0.f;
         SQ[row * M2 + col] = v;
         SQ[col * M2 + row] = v;
+        finite &= fabsf(crit[r]) <= 3.0e38f;
       }
     }
     __syncthreads();
-    for (int e = tid; e < M2 * M2; e += NT) {
-      const float v = SQ[e][0];
-      finite &= fabsf(v) <= 3.0e38f;
-      if (e / M2 == e % M2) my_dm = fmaxf(my_dm, fabsf(v));
-    }
   }
   JTS(4);
   if (p.step_d >= 0) {
@@ -1418,8 +1425,7 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_
   if (b < n_d) {
     const int m = b / npair, g = b % npair;
     JTS(0);
-    if (p.st[m].done || (p.dbg & 2)) return;
-    jacobi_fused_d<M2>(p, m, g, jsm);
+    jacobi_fused_d<M2>(p, m, g, jsm);               // (checks the matrix' done flag itself, after issuing its loads)
   } else {
     b -= n_d;
     const int task = b / p.nmat, m = b % p.nmat;
