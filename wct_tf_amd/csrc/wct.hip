@@ -1630,7 +1630,10 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
 // partial[m][chunk][0..3] = strict sum (half the sum over the ordered pairs of the chunk's rows), kept diagonals,
 // lenient sum, significant diagonals.  Fixed thread -> element map and reduction order: bit-reproducible, so the
 // sweep count -- and with it every output bit -- does not depend on scheduling.
-__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const JacobiState* st, float* partial, int C) {
+// mixed_w: weight of the kept-x-dropped couplings in the STRICT measure.  The second-order completion covers the block of
+// kept eigenvalues only, so when the stop threshold is raised for it (4e-2 instead of 1.5e-2) the couplings across the
+// cut-off keep their old bound: their squared measure is weighted by (4 / 1.5)^2.
+__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const JacobiState* st, float* partial, int C, float mixed_w = 1.f) {
   __shared__ float red[4][4];
   __shared__ float dg[1024];                           // |a_ii| of the whole matrix (C <= 1024)
   __shared__ float idg[1024];                          // 1 / |a_ii| (0 for a zero diagonal: such pairs take the `mixed` form)
@@ -1641,12 +1644,16 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
   const float floor_m = st[m].floor;
   const int rows = (C + JACOBI_RESID_CHUNKS - 1) / JACOBI_RESID_CHUNKS;
   const int p0 = ch * rows, p1 = min(C, p0 + rows);
+  int near = 0;
   for (int i = tid; i < C; i += 256) {
     const float d = fabsf(Am[(size_t)i * C + i]);
     dg[i] = d;
     idg[i] = d > 0.f ? 1.f / d : 0.f;
+    near |= (d > 3.3e-6f) & (d < 3e-5f);
   }
-  __syncthreads();
+  // an eigenvalue within half a decade of the cut-off: its kept / dropped side can still change, and a pair of the kept
+  // block may really be a pair across the cut-off -- such a matrix keeps the old bound on ALL its couplings
+  const float kk_w = __syncthreads_or(near) ? mixed_w : 1.f;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   for (int q = tid; q < C; q += 256) {                 // at most four columns per thread; rows stream coalesced
     const float dq = dg[q], iq = idg[q];
@@ -1662,7 +1669,7 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
       const float e2 = p == q ? 0.f : 0.5f * e * e;
       const float cos2 = e2 * ip * iq;
       const float mixed = e2 * ibig * (ibig + (small < 1e-5f ? 0.01f * 1e5f : 0.f));
-      v[0] += (kp & kq) ? cos2 : ((kp | kq) ? mixed : 0.f);
+      v[0] += (kp & kq) ? kk_w * cos2 : ((kp | kq) ? mixed_w * mixed : 0.f);
       v[2] += (sp & sq) ? cos2 : ((sp | sq) ? mixed : 0.f);
     }
   }
@@ -1745,7 +1752,8 @@ __global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, i
     printf("jacobi m=%d done=%d sweeps=%d last_sig=%.3e r2=%.3e r2l=%.3e floor=%.3e\n", m, st[m].done, st[m].sweeps, __uint_as_float(st[m].last_sig), st[m].r2, st[m].r2l, st[m].floor);
   // out of sweeps: good enough after all if the last sweep's significant pairs were below tol_max, or if the lenient
   // residual is within 4x of the target (second-order error 16x the target's: still inside the 1e-3 budget)
-  const float tol_l = tol_fn > 0.f ? 4.f * tol_fn : tol_max;
+  // (second-order completion: error ~ r^3, and its stop threshold is already 4e-2 -- twice that is the most the 1e-3 budget takes)
+  const float tol_l = tol_fn > 0.f ? (tol_fn > 2e-2f ? 2.f : 4.f) * tol_fn : tol_max;
   if (d == 0 && (__uint_as_float(st[m].last_sig) < tol_max || (st[m].r2l >= 0.f && st[m].r2l < tol_l * tol_l))) d = 1;
   if (m < nmat && sweeps_out) sweeps_out[m] = d == 1 ? st[m].sweeps : (d == 2 ? -1000 - st[m].sweeps : -st[m].sweeps);
   const int n_open = __builtin_popcountll(__ballot(d == 0)), n_nan = __builtin_popcountll(__ballot(d == 2));
@@ -1885,12 +1893,12 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
     if (mid_from >= 0 && sweep >= mid_from)
       for (int g = 0; g < ngrp; ++g)
         if (grp[g].tol_fn > 0.f) {
-          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C);
+          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
           hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, 0);
         }
     jacobi_enqueue_steps<M2>(grp, ngrp, C, half, nblk - 1);
     for (int g = 0; g < ngrp; ++g) {
-      hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C);
+      hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
       hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, 0, 0, max_sweeps - 3);
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
@@ -2067,7 +2075,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     if (mid) {
       for (int g = 0; g < ngrp; ++g)
         if (grp[g].tol_fn > 0.f) {
-          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C);
+          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
           hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, grp[g].cur, grp[g].segs);
         }
       if ((rc = jacobi_segment_begin(grp, ngrp))) return rc;
@@ -2075,7 +2083,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
       if ((rc = jacobi_segment_end<M2>(grp, ngrp, C, half, nblk - 1))) return rc;
     }
     for (int g = 0; g < ngrp; ++g) {
-      hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C);
+      hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
       hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, max_sweeps - 3);
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
@@ -2190,8 +2198,67 @@ __global__ void spectral_matrix_kernel(const float* A, float* G, int C, size_t s
   }
 }
 
+// Second-order term of the same expansion (round 3):  (L2)_pq = sum_k f[d_p, d_k, d_q] E_pk E_kq  with the second divided
+// differences of the spectral functions, which have closed forms without cancellation (sa = sqrt(a + shift) ...):
+//   l^+1/2:  f[a,b,c] = -1 / ((sa+sb)(sb+sc)(sa+sc))
+//   l^-1/2:  f[a,b,c] = (sa+sb+sc) / (sa sb sc (sa+sb)(sb+sc)(sa+sc))
+// and both SEPARATE into matrix products of elementwise-scaled copies of E:  with N_pk = E_pk / (s_p + s_k),
+// R_pk = E_pk / s_k, P_pk = N_pk / s_k,
+//   l^+1/2:  L2 = -(N N) o 1/(s_p + s_q)
+//   l^-1/2:  L2 = ( sym(R N) + (s_p + s_q)/2 (P N) ) o 1/(s_p s_q (s_p + s_q))      (P N = N diag(1/s) N is symmetric)
+// (checked against an exact eigendecomposition in NumPy: the error of f(D + E) drops from ~r^2 to ~r^3).  Only the block
+// of kept eigenvalues takes part: a dropped direction's couplings are bounded by sqrt(1e-5 d_p) tol and enter squared.
+// It lets the sweeps stop one sweep earlier for the same transform error (profiles/r03_eig_calibration.txt).
+__global__ void spectral_prep2_kernel(const float* A, float* N, float* R, float* Pm, int C, size_t stride, int kind, float shift) {
+  const int m = blockIdx.y;
+  const size_t cc = (size_t)C * C;
+  const float* Am = A + m * stride;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i / C), k = (int)(i % C);
+    const float dp = Am[(size_t)p * C + p], dk = Am[(size_t)k * C + k];
+    float n = 0.f, r = 0.f, pm = 0.f;
+    if (p != k && dp > 1e-5f && dk > 1e-5f) {
+      const float e = 0.5f * (Am[i] + Am[(size_t)k * C + p]);
+      const float sp = sqrtf(dp + shift), sk = sqrtf(dk + shift);
+      n = e / (sp + sk);
+      r = e / sk;
+      pm = n / sk;
+    }
+    N[m * cc + i] = n;
+    if (kind == 0) { R[m * cc + i] = r; Pm[m * cc + i] = pm; }
+  }
+}
+
+__global__ void spectral_add2_kernel(const float* A, float* G, const float* X1, const float* X2, int C, size_t stride, int kind, float shift) {
+  const int m = blockIdx.y;
+  const size_t cc = (size_t)C * C;
+  const float* Am = A + m * stride;
+  float* Gm = G + m * stride;
+  // a matrix with an eigenvalue within half a decade of the cut-off keeps the first-order completion and the old stop
+  // threshold (jacobi_resid_kernel weighs its residual accordingly): around the cut-off sit the noise directions of
+  // rank-deficient covariances, whose mutual couplings never become small, and a second-order sum over them is noise
+  int near = 0;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    const float d = fabsf(Am[(size_t)i * C + i]);
+    near |= (d > 3.3e-6f) & (d < 3e-5f);
+  }
+  if (__syncthreads_or(near)) return;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i / C), q = (int)(i % C);
+    const float dp = Am[(size_t)p * C + p], dq = Am[(size_t)q * C + q];
+    if (!(dp > 1e-5f && dq > 1e-5f)) continue;
+    const float sp = sqrtf(dp + shift), sq = sqrtf(dq + shift);
+    const size_t t = (size_t)q * C + p;
+    float l2;
+    if (kind == 1) l2 = -0.5f * (X2[m * cc + i] + X2[m * cc + t]) / (sp + sq);
+    else l2 = (0.5f * (X1[m * cc + i] + X1[m * cc + t]) + 0.25f * (sp + sq) * (X2[m * cc + i] + X2[m * cc + t])) / (sp * sq * (sp + sq));
+    Gm[i] += l2;
+  }
+}
+
+// 0: spectral functions of the diagonal only, 1: + first-order completion, 2 (default): + second-order completion
 static int eig_correct_enabled() {
-  static const int on = getenv("WCT_EIG_CORRECT") ? atoi(getenv("WCT_EIG_CORRECT")) : 1;
+  static const int on = getenv("WCT_EIG_CORRECT") ? atoi(getenv("WCT_EIG_CORRECT")) : 2;
   return on;
 }
 // residual at which the WCT path stops sweeping.  Calibrated on the level features of a 512x512 frame
@@ -2199,17 +2266,35 @@ static int eig_correct_enabled() {
 // without the first-order completion and ~0.8 r2 (+ ~3e-5 from the other stages) with it, so 1.5e-2 bounds the
 // completed transform's error by ~1.8e-4 -- five times inside the 1e-3 budget.  0 without the completion.
 constexpr float JACOBI_TOL_FN = 1.5e-2f;
+constexpr float JACOBI_TOL_FN2 = 4e-2f;            // with the second-order completion (profiles/r03_eig_calibration.txt: the transform error
+                                                   // at 4e-2 with it, 3.1e-5 .. 1.3e-4, is what 1.5e-2 gave without it, one sweep later)
 static float jacobi_tol_fn() {
-  static const float t = getenv("WCT_JACOBI_TOL_FN") ? (float)atof(getenv("WCT_JACOBI_TOL_FN")) : (eig_correct_enabled() ? JACOBI_TOL_FN : 0.f);
+  static const float t = getenv("WCT_JACOBI_TOL_FN") ? (float)atof(getenv("WCT_JACOBI_TOL_FN"))
+                                                     : (eig_correct_enabled() >= 2 ? JACOBI_TOL_FN2 : (eig_correct_enabled() ? JACOBI_TOL_FN : 0.f));
   return t;          // an explicit WCT_JACOBI_TOL_FN also applies without the completion (calibration runs)
 }
 
 // out[b] = V[b] G[b] V[b]^T for nbatch matrices (strides in elements); X: scratch of the same shape as G
+// scratch2: 5 * nbatch * C * C floats for the second-order completion (or null: first order at most)
 static int launch_spectral_function(const float* A, const float* V, float* G, float* X, float* out, int C, int nbatch,
-                                    size_t stride, size_t out_stride, int kind, float shift, hipStream_t s) {
+                                    size_t stride, size_t out_stride, int kind, float shift, hipStream_t s, float* scratch2 = nullptr) {
   const size_t cc = (size_t)C * C;
-  hipLaunchKernelGGL(spectral_matrix_kernel, dim3((unsigned)(cc >= 65536 ? 64 : (cc + 255) / 256), nbatch), dim3(256), 0, s,
-                     A, G, C, stride, kind, shift, eig_correct_enabled());
+  const unsigned ew = (unsigned)(cc >= 65536 ? 64 : (cc + 255) / 256);
+  hipLaunchKernelGGL(spectral_matrix_kernel, dim3(ew, nbatch), dim3(256), 0, s, A, G, C, stride, kind, shift, eig_correct_enabled());
+  if (scratch2 && eig_correct_enabled() >= 2) {
+    float* N = scratch2; float* R = N + nbatch * cc; float* Pm = R + nbatch * cc; float* X1 = Pm + nbatch * cc; float* X2 = X1 + nbatch * cc;
+    hipLaunchKernelGGL(spectral_prep2_kernel, dim3(ew, nbatch), dim3(256), 0, s, A, N, R, Pm, C, stride, kind, shift);
+    GemmArgs a = {};   // X2 = (kind 1: N, kind 0: P) N
+    a.A = kind == 1 ? N : Pm; a.lda = C; a.a_kmajor = 0; a.B = N; a.ldb = C; a.b_kmajor = 1; a.sA = a.sB = cc;
+    a.M = C; a.N = C; a.K = C; a.ksplit = C; a.out32 = X2; a.ldo = C; a.s_out = cc;
+    int rc2 = launch_gemm(a, 1, nbatch, s);
+    if (rc2) return rc2;
+    if (kind == 0) {
+      a.A = R; a.out32 = X1;   // X1 = R N
+      if ((rc2 = launch_gemm(a, 1, nbatch, s))) return rc2;
+    }
+    hipLaunchKernelGGL(spectral_add2_kernel, dim3(ew, nbatch), dim3(256), 0, s, A, G, X1, X2, C, stride, kind, shift);
+  }
   GemmArgs g = {};   // X = V G
   g.A = V; g.lda = C; g.a_kmajor = 0; g.B = G; g.ldb = C; g.b_kmajor = 1; g.sA = g.sB = stride;
   g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = X; g.ldo = C; g.s_out = stride;
@@ -2438,7 +2523,7 @@ __global__ __launch_bounds__(256, 2) void apply_f16x2_kernel(ApplyArgs p) {
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WctCarve {
-  float *mean, *var, *stat_partial, *absmax, *scale, *cov_partial, *A, *V, *d, *G, *X, *Tw, *Tcs, *T, *M, *bias;
+  float *mean, *var, *stat_partial, *absmax, *scale, *cov_partial, *A, *V, *d, *G, *X, *S2, *Tw, *Tcs, *T, *M, *bias;
   unsigned* mabs;
   void* jacobi_ws; size_t jacobi_bytes;
   int nslab, nsplit, ksplit;
@@ -2480,6 +2565,7 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   w.d = (float*)take((size_t)2 * P * C * sizeof(float));
   w.G = (float*)take(2 * P * cc);
   w.X = (float*)take(2 * P * cc);
+  w.S2 = (float*)take(5 * P * cc);
   w.Tw = (float*)take(P * cc);
   w.Tcs = (float*)take(P * cc);
   w.T = (float*)take(P * cc);
@@ -2594,8 +2680,8 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
     // Tw = Vc f_c(Ac) Vc^T, Tcs = Vs f_s(As) Vs^T with the first-order completion of f on the residual off-diagonals;
     // the wct_np semantics shift the kept eigenvalues by eps inside the gains (ops.py:114,127), wct_tf does not
     const float shift = mode == WCT_MODE_NP ? (eps_in >= 0.f ? eps_in : 1e-5f) : 0.f;
-    if ((rc = launch_spectral_function(w.A, w.V, w.G, w.X, w.Tw, C, P, 2 * cc, cc, 0, shift, s))) return rc;
-    if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.Tcs, C, shared_style ? 1 : P, 2 * cc, cc, 1, shift, s))) return rc;
+    if ((rc = launch_spectral_function(w.A, w.V, w.G, w.X, w.Tw, C, P, 2 * cc, cc, 0, shift, s, w.S2))) return rc;
+    if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.Tcs, C, shared_style ? 1 : P, 2 * cc, cc, 1, shift, s, w.S2))) return rc;
   }
   {
     GemmArgs g = {};   // T = Tcs . Tw
@@ -2824,9 +2910,9 @@ int launch_style_swap(const float* content, int hc, int wc, const float* style, 
   const size_t cc = (size_t)C * C;
   // content whitening, style whitening, style colouring: S^-1/2 | S^1/2 over the kept singular values, no eps in the
   // gains (ops.py:187-189,197-198,208-209), with the first-order completion on the solver's residual
-  if ((rc = launch_spectral_function(w.A, w.V, w.G, w.X, w.Tw, C, 1, 2 * cc, cc, 0, 0.f, s))) return rc;
-  if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.Tcs, C, 1, 2 * cc, cc, 0, 0.f, s))) return rc;
-  if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.T, C, 1, 2 * cc, cc, 1, 0.f, s))) return rc;
+  if ((rc = launch_spectral_function(w.A, w.V, w.G, w.X, w.Tw, C, 1, 2 * cc, cc, 0, 0.f, s, w.S2))) return rc;
+  if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.Tcs, C, 1, 2 * cc, cc, 0, 0.f, s, w.S2))) return rc;
+  if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.T, C, 1, 2 * cc, cc, 1, 0.f, s, w.S2))) return rc;
   auto apply = [&](const float* X, int N, const float* mean, const float* T, float* out) {   // out = (X - mean) T^T
     GemmArgs g = {};
     g.A = X; g.lda = C; g.a_kmajor = 0; g.a_sub_k = mean; g.B = T; g.ldb = C; g.b_kmajor = 0;
