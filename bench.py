@@ -383,7 +383,7 @@ def main():
                 'bound': 'latency of the serial rotation sets (LDS write path) + fp32-MFMA tile updates',
                 'note': 'batched two-sided block Jacobi on the %d-level covariances (C = 512, 512, 256, 128, 64; content and style); '
                         'look-ahead launches {pair problems of step s, tile update of step s-1}, V resident in registers per '
-                        'launch segment from 8 matrices on; second-largest time class' % len(LEVELS)}
+                        'launch segment from 24 matrices per solve on, second-order completion of the spectral functions; second-largest time class' % len(LEVELS)}
             line['breakdown_ms_per_step'] = {k: v['ms'] / args.steps for k, v in prof.items()}
         if world == 1 and not args.no_latency and not args.shared_style:
             line.update(latency_leg(ctx, S, args.alpha))

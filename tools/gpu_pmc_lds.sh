@@ -2,7 +2,7 @@
 # LDS / issue-stall counters per kernel (one PMC pass): SQ_LDS_IDX_ACTIVE (LDS-array cycles), SQ_LDS_BANK_CONFLICT, SQ_INSTS_LDS,
 # SQ_INSTS_VALU, SQ_WAIT_INST_ANY, SQ_WAIT_INST_LDS, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES -> gpurun_out/<tag>_pmc_lds.csv
 export TMPDIR=/tmp
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 R=$GRAFT_REPO_ROOT
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_lds -o lds -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-prof > /tmp/pmc_lds.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-layer conv table and batch sweep of the final build -> gpurun_out/<tag>_conv_layers_b8.txt, <tag>_batch_sweep.txt
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 cd $GRAFT_REPO_ROOT
 ( echo "# python tools/bench_conv.py 8  (per-layer HIP-event timing of the conv3x3 kernel, fp32-output variant, batch 8 emulated by an 8x taller image)"; python tools/bench_conv.py 8 2>/dev/null ) > gpurun_out/${TAG}_conv_layers_b8.txt
 ( echo "# python bench.py --batch B --steps 5 --warmup 2 --no-cpu-baseline --no-latency   (device-resident pairs per step; per-class event timing on)"

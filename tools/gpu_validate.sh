@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round validation on the GPU box: full GPU test suite, the default bench line, smoke(), then the profile passes.
 # usage (gpurun): bash tools/gpu_validate.sh <tag>
-TAG=${1:-r02_final}
+TAG=${1:-r03_final}
 cd $GRAFT_REPO_ROOT
 ( python -m pytest tests/ -x -q -m gpu 2>&1 | tail -60; echo "pytest rc=${PIPESTATUS[0]}" ) > gpurun_out/${TAG}_pytest_gpu.log 2>&1
 tail -3 gpurun_out/${TAG}_pytest_gpu.log
