@@ -70,6 +70,8 @@ struct wct_ctx {
   DevBuf train_ws;
   Decoder dec[6];
   DevBuf act[2], feat_c, feat_s[6], img_c, img_s, img_t[2], wct_out, wct_ws, stage[4];
+  DevBuf usum_c, usum_s[6], umax;     // feature statistics from the tap epilogues (ConvArgs::usum / umax); umax: [7][32][UMAX_SLOTS] words
+
   int* eig_fail = nullptr;         // pinned host memory mapped into the device: [4 stream groups][2] eigenproblems that did
                                    // (then [4 groups][6 size classes][3] solver statistics: matrices, sweeps, max sweeps)
   int* eig_fail_dev = nullptr;     // not converge / had non-finite input -- bumped by jacobi_finalize_kernel
@@ -196,6 +198,9 @@ extern "C" void wct_destroy(wct_ctx* c) {
                     &c->wct_out, &c->wct_ws, &c->stage[0], &c->stage[1], &c->stage[2], &c->stage[3]};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   for (auto& b : c->feat_s) if (b.p) hipFree(b.p);
+  for (auto& b : c->usum_s) if (b.p) hipFree(b.p);
+  if (c->usum_c.p) hipFree(c->usum_c.p);
+  if (c->umax.p) hipFree(c->umax.p);
   for (auto& r : c->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   for (auto& e : c->free_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (c->eig_fail) hipHostFree(c->eig_fail);
@@ -495,9 +500,9 @@ static int check_min_size(const char* what, int H, int W, int level) {
 
 
 static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16, float* y32,
-                    int B, int H, int W, int upsample, int relu, int pool = 0) {
+                    int B, int H, int W, int upsample, int relu, int pool = 0, float* usum = nullptr, unsigned* umax = nullptr) {
   ConvArgs a;
-  a.x = x; a.w = l.w; a.bias = l.b; a.y16 = y16; a.y32 = y32;
+  a.x = x; a.w = l.w; a.bias = l.b; a.y16 = y16; a.y32 = y32; a.usum = usum; a.umax = umax;
   a.B = B; a.H = H; a.W = W; a.Cin = l.cin; a.Cout = l.cout; a.upsample = upsample; a.relu = relu; a.pool = pool;
   const double px = (double)B * H * W;
   const double in_px = upsample ? px / 4 : px;
@@ -508,8 +513,9 @@ static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16
 }
 
 // img: [B][H][W][3] fp32 device.  taps32[l] (l=1..5): fp32 feature output for relu<l>_1 or null.
+// usum / umax (optional, per level like taps32): statistics of the tap, taken by the epilogue that writes it
 static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int clamp01, int deepest,
-                       float* const taps32[6]) {
+                       float* const taps32[6], float* const* usum = nullptr, unsigned* const* umax = nullptr) {
   if (!c->enc_loaded) { wct_set_error("encoder weights not set (wct_set_encoder)"); return WCT_ERR_STATE; }
   ARG_CHECK(deepest >= 1 && deepest <= 5 && H >= 2 && W >= 2);
   const size_t act_bytes = (size_t)B * H * W * 64 * sizeof(half_t);
@@ -522,6 +528,7 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
     a.x = img; a.wfrag = c->first_w; a.bias = c->first_b;
     a.y16 = deepest > 1 ? cur : nullptr; a.y32 = taps32[1];
     a.B = B; a.H = H; a.W = W; a.clamp01 = clamp01;
+    a.usum = usum && taps32[1] ? usum[1] : nullptr; a.umax = a.usum ? umax[1] : nullptr;
     const double px = (double)B * H * W;
     ProfScope ps(c, 1, 2.0 * px * 27 * 64, px * (12 + 64 * ((a.y16 ? 2 : 0) + (a.y32 ? 4 : 0))));
     TRY(launch_conv_first(a, c->stream));
@@ -539,7 +546,8 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
     const int tap = seq_tap[i];
     const bool last = tap == deepest;
     const bool fuse = pool_after[i] && fuse_pool;
-    TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1, fuse));
+    float* const us = tap && taps32[tap] && usum ? usum[tap] : nullptr;
+    TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1, fuse, us, us ? umax[tap] : nullptr));
     half_t* t = cur; cur = nxt; nxt = t;
     if (last) break;
     if (pool_after[i]) {
@@ -585,18 +593,19 @@ static int run_decoder(wct_ctx* c, int level, const half_t* feat16, int B, int h
 }
 
 static int run_transform(wct_ctx* c, const float* fc, int Nc, const float* fs, int Ns, int C, int P,
-                         float alpha, unsigned flags, float eps, half_t* out16, float* out32, int* sweeps_dev) {
+                         float alpha, unsigned flags, float eps, half_t* out16, float* out32, int* sweeps_dev,
+                         const WctFeatStats* st = nullptr) {
   const int shared = (flags & WCT_FLAG_STYLE_SHARED) ? 1 : 0;
   const size_t ws = wct_workspace_bytes(C, Nc, Ns, P);
   TRY(ensure(c, c->wct_ws, ws));
   if (flags & WCT_FLAG_ADAIN) {
     ProfScope ps(c, 7, 0, (double)P * (2.0 * Nc + 2.0 * Ns) * C * 4 + (double)P * Nc * C * 6);
-    return launch_adain(fc, Nc, fs, Ns, C, P, alpha, 1e-5f, out16, out32, c->wct_ws.p, c->wct_ws.cap, c->stream, shared);
+    return launch_adain(fc, Nc, fs, Ns, C, P, alpha, 1e-5f, out16, out32, c->wct_ws.p, c->wct_ws.cap, c->stream, shared, st);
   }
   const int mode = (flags & WCT_FLAG_MODE_NP) ? WCT_MODE_NP : WCT_MODE_TF;
   {
     ProfScope ps(c, 4, (double)P * 2.0 * C * C * ((double)Nc + Ns), (double)P * 2.0 * ((double)Nc + Ns) * C * 4);
-    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, 0, nullptr, nullptr, shared, c->eig_fail_dev));
+    TRY(launch_wct(fc, Nc, fs, Ns, C, P, alpha, mode, eps, out16, out32, c->wct_ws.p, c->wct_ws.cap, sweeps_dev, WCT_STAGE_COV, c->stream, nullptr, 0, nullptr, nullptr, shared, c->eig_fail_dev, st));
   }
   {
     ProfScope ps(c, 5, 0, 0);
@@ -852,16 +861,31 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
     TRY(launch_u8_to_f32(style, (float*)c->img_s.p, ns, c->stream));
     img_c = (const float*)c->img_c.p; img_s = (const float*)c->img_s.p;
   }
+  // The per-channel sums and the largest value of every tap come out of the epilogue that writes it (16-pixel unit sums,
+  // ConvArgs::usum): the transform's statistics pass then reads 1/16 of the feature bytes.  Needs a feature width that is
+  // a multiple of 16; other widths (and WCT_FUSE_STATS=0) take the sums from the stored features -- the same bits.
+  static const int fuse_stats = getenv("WCT_FUSE_STATS") ? atoi(getenv("WCT_FUSE_STATS")) : 1;
+  const bool want_stats = fuse_stats != 0;
+  constexpr size_t UROW = 32 * UMAX_SLOTS;                           // words per row: 32 images
+  TRY(ensure(c, c->umax, 7 * UROW * sizeof(unsigned)));
+  unsigned* const umax_c = (unsigned*)c->umax.p;                    // row 0: content (per level), rows 1..5: style levels
+  if (want_stats) HIP_TRY(hipMemsetAsync(c->umax.p, 0, 7 * UROW * sizeof(unsigned), c->stream));
   // ONE style pass with a tap per requested level (model.py:69-75)
   float* taps[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* us_s[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned* um_s[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int i = 0; i < n_levels; ++i) {
     const int l = levels[i];
     int h, w;
     level_dims(Hs, Ws, l, &h, &w);
     TRY(ensure(c, c->feat_s[l], (size_t)Bs * h * w * LEVEL_C[l] * 4));
     taps[l] = (float*)c->feat_s[l].p;
+    if (want_stats && w % 16 == 0) {
+      TRY(ensure(c, c->usum_s[l], (size_t)Bs * h * (w / 16) * LEVEL_C[l] * 4));
+      us_s[l] = (float*)c->usum_s[l].p; um_s[l] = umax_c + UROW * l;
+    }
   }
-  TRY(run_encoder(c, img_s, Bs, Hs, Ws, 0, deepest, taps));
+  TRY(run_encoder(c, img_s, Bs, Hs, Ws, 0, deepest, taps, us_s, um_s));
 
   const float* cur = img_c;
   int H = Hc, W = Wc;
@@ -873,8 +897,17 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
     TRY(ensure(c, c->feat_c, (size_t)B * h * w * C * 4));
     float* ctaps[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ctaps[l] = (float*)c->feat_c.p;
+    float* us_c[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned* um_c[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (want_stats && w % 16 == 0) {
+      TRY(ensure(c, c->usum_c, (size_t)B * h * (w / 16) * C * 4));
+      us_c[l] = (float*)c->usum_c.p; um_c[l] = umax_c;
+      if (i > 0) HIP_TRY(hipMemsetAsync(umax_c, 0, UROW * sizeof(unsigned), c->stream));
+    }
+    WctFeatStats st;
+    st.u[0] = us_c[l]; st.umax[0] = um_c[l]; st.u[1] = us_s[l]; st.umax[1] = um_s[l];
     // level i>0 encodes clip(previous decoded, 0, 1) (model.py:86): the clamp is in the conv1_1 loader
-    TRY(run_encoder(c, cur, B, H, W, i > 0, l, ctaps));
+    TRY(run_encoder(c, cur, B, H, W, i > 0, l, ctaps, us_c, um_c));
     TRY(ensure(c, c->wct_out, (size_t)B * h * w * C * 2));
     if (l == 5 && (flags & WCT_FLAG_SWAP5)) {
       // tf.case priority at relu5_1: swap5 > adain > wct (model.py:148-154); pairs one at a time
@@ -888,7 +921,7 @@ extern "C" int wct_stylize_batch_dev(wct_ctx* c, const uint8_t* content, int Hc,
                               c->wct_ws.p, c->wct_ws.cap, c->stream, c->eig_fail_dev));
     } else
     TRY(run_transform(c, (float*)c->feat_c.p, h * w, (float*)c->feat_s[l].p, hs * ws, C, B, alpha, flags, -1.f,
-                      (half_t*)c->wct_out.p, nullptr, nullptr));
+                      (half_t*)c->wct_out.p, nullptr, nullptr, &st));
     const int scale = 1 << (l - 1);
     const int H2 = h * scale, W2 = w * scale;
     DevBuf& dst = c->img_t[i & 1];
@@ -1093,7 +1126,7 @@ extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B,
   {  // encoder over the decoded image (not clipped in training: model.py:176), pools as separate kernels
     ConvFirstArgs a;
     a.x = D; a.wfrag = c->first_w; a.bias = c->first_b; a.y16 = level > 1 ? e0 : nullptr; a.y32 = level == 1 ? Fp : nullptr;
-    a.B = B; a.H = H; a.W = W; a.clamp01 = 0;
+    a.B = B; a.H = H; a.W = W; a.clamp01 = 0; a.usum = nullptr; a.umax = nullptr;
     TRY(launch_conv_first(a, s));
     const half_t* cur = e0;
     for (auto& es : enc_steps) {

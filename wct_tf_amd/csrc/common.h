@@ -51,7 +51,26 @@ struct ConvArgs {
   int upsample;        // input is the x2 nearest upsample of x (model.py:293)
   int relu;
   int pool;            // fuse the following 2x2/2 'same' max-pool: outputs are [(H+1)/2][(W+1)/2][Cout]
+  // feature statistics from the fp32 epilogue (null: off; need y32, relu, W % 16 == 0): usum [B][H*W/16][Cout] = the sum of
+  // every run of 16 consecutive pixels (unit_row_sum's fixed tree -- what colsum_kernel computes from the stored features),
+  // umax [B][UMAX_SLOTS] = bit patterns whose maximum is the largest value of the image (>= 0 after the ReLU), merged with
+  // atomicMax: zero it before the launch
+  float* usum;
+  unsigned* umax;
 };
+// The maxima of an image are merged into UMAX_SLOTS words (two cache lines) instead of one: tens of thousands of
+// wavefronts bumping ONE word -- or 32 words of one cache line -- serialise in a single L2 channel (measured: +94 us per
+// launch); a wave also reads its slot first and skips the atomic when it cannot raise it (values only grow).
+constexpr int UMAX_SLOTS = 64;
+__device__ __forceinline__ void umax_merge(unsigned* umax_img, int slot, float vmax, int lane) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+  if (lane == 0) {
+    unsigned* w = umax_img + (slot & (UMAX_SLOTS - 1));
+    const unsigned bits = __builtin_bit_cast(unsigned, vmax);
+    if (bits > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, bits);
+  }
+}
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
 
 struct ConvFirstArgs {   // 3 -> 64 with the 1x1 'preprocess' folded in
@@ -62,7 +81,32 @@ struct ConvFirstArgs {   // 3 -> 64 with the 1x1 'preprocess' folded in
   float* y32;
   int B, H, W;
   int clamp01;         // clip(x,0,1) at load (model.py:86)
+  float* usum;         // as in ConvArgs (with y32; W % 16 == 0)
+  unsigned* umax;
 };
+
+// Sums over the 16 lanes of a DPP row (= the 16 pixels of one row of an MFMA pixel tile), the same bits in every
+// lane: ((p0+p1)+(p2+p3) + (p4+p5)+(p6+p7)) + (the same of p8..p15).  colsum_kernel adds 16 consecutive feature rows in
+// exactly this tree, so statistics taken in a conv epilogue and statistics taken from the stored features agree bit for bit.
+// Four values at once (the clang DPP builtin costs a v_mov_b32_dpp + v_add_f32 per step; written out, a step is one
+// v_add_f32_dpp, and interleaving the four chains covers the VALU-write -> DPP-read wait states; the leading s_nop
+// covers the writer of the inputs).  dst = dpp(src0) + src1 with all three the same register.
+__device__ __forceinline__ void unit_row_sum4(f32x4& t) {
+  float a = t[0], b = t[1], c = t[2], d = t[3];
+#define WCT_DPP_STEP(ctrl)                                                             \
+  "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"       \
+  "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"       \
+  "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"       \
+  "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+  asm volatile("s_nop 1\n"
+               WCT_DPP_STEP("quad_perm:[1,0,3,2]")
+               WCT_DPP_STEP("quad_perm:[2,3,0,1]")
+               WCT_DPP_STEP("row_half_mirror")
+               WCT_DPP_STEP("row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+#undef WCT_DPP_STEP
+  t[0] = a; t[1] = b; t[2] = c; t[3] = d;
+}
 int launch_conv_first(const ConvFirstArgs& a, hipStream_t s);
 
 struct ConvLastArgs {    // 64 -> 3, no activation (model.py:298)
@@ -105,6 +149,10 @@ int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s);
 // Feature matrices are pixel-major: X[n][c] (NHWC flattened), fp32.
 enum { WCT_MODE_NP = 0, WCT_MODE_TF = 1 };
 
+// Statistics a conv epilogue took while it wrote a feature map (ConvArgs::usum / umax): [0] content, [1] style; a side
+// whose u is null is summed from the features themselves (same bits either way, colsum_kernel).
+struct WctFeatStats { const float* u[2]; const unsigned* umax[2]; };
+
 // P independent whiten-colour transforms on `s`:  out = blend(T (x - mc) + ms)
 // content [P][Nc][C], style [P][Ns][C]; out16/out32 [P][Nc][C] (either may be null).
 size_t wct_workspace_bytes(int C, int Nc, int Ns, int P);
@@ -116,11 +164,13 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
                int shared_style /* style holds ONE feature map used by all P pairs: its statistics and
                                    eigensystem are computed once */,
                int* eig_fail /* device-visible status words [4 stream groups][2] (not converged, non-finite), bumped by the
-                                eigensolver, or null */);
+                                eigensolver, or null */,
+               const struct WctFeatStats* stats = nullptr /* unit sums / maxima a conv epilogue left beside the features */);
 enum { WCT_STAGE_COV = 1, WCT_STAGE_EIG = 2, WCT_STAGE_APPLY = 4, WCT_STAGE_ALL = 7 };
 int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P,
                  float alpha, float eps, half_t* out16, float* out32,
-                 void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style);
+                 void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style,
+                 const struct WctFeatStats* stats = nullptr);
 // Symmetric eigensolver (batched): A [nmat][C][C] is overwritten (diag -> eigenvalues),
 // V [nmat][C][C] gets eigenvectors in columns.  C multiple of 32, 32 <= C <= 1024.
 // sweeps_done_dev[m]: sweeps used (> 0) if matrix m converged, -sweeps if it was still rotating when the sweep

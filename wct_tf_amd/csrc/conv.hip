@@ -83,6 +83,10 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)
   const h2 lo2 = {(half_t)lo1, (half_t)lo1};
   const int ox = x0 + frag_px;
   const int chan = n0 + wn * NT * 32;        // first channel of this wave; + nt*32 (+ 8 rq / 16 m) are immediates
+  // feature statistics (ConvArgs::usum / umax): per run of 16 pixels the channel sums, per image the largest value
+  const bool stats = OUT32 && p.usum != nullptr;
+  float* const us = stats ? p.usum + (size_t)b * (p.H * (p.W >> 4)) * p.Cout + chan + 4 * kgrp : nullptr;
+  float vmax = 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int oy = y0 + (wm * MT + mt) * 2 + frag_py;
@@ -103,6 +107,15 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo1);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r32, off32 + (nt * 32 + 8 * rq) * 4, 0, 0);
+          if (stats) {                         // uniform; W % 16 == 0: a tile row is a run of 16 pixels of the flattened map
+            f32x4 t = v;
+            unit_row_sum4(t);
+            if (in_img) {
+              vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+              if (frag_px == 0)
+                *reinterpret_cast<f32x4*>(us + (size_t)(oy * (p.W >> 4) + (x0 >> 4)) * p.Cout + nt * 32 + 8 * rq) = t;
+            }
+          }
         }
         h2 lo = {(half_t)v[0], (half_t)v[1]}, hi = {(half_t)v[2], (half_t)v[3]};
         if (!OUT32) {
@@ -139,6 +152,8 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)
       }
     }
   }
+  // values are >= 0 (ReLU): the bit patterns order like the values
+  if (stats) umax_merge(p.umax + b * UMAX_SLOTS, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), vmax, lane);
 }
 
 template <int MT, int NT>
@@ -382,6 +397,7 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   // one image's activations are addressed with 32-bit byte offsets (buffer loads)
   ARG_CHECK((size_t)a.H * a.W * a.Cin * 2 < ((size_t)1 << 31));
   ARG_CHECK((size_t)a.H * a.W * a.Cout * (a.y32 ? 4 : 2) < ((size_t)1 << 31));     // per-image output buffers (epilogue)
+  ARG_CHECK(!a.usum || (a.y32 && a.umax && a.relu && a.W % 16 == 0));
   ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
   static const int force = getenv("WCT_CONV_CFG") ? atoi(getenv("WCT_CONV_CFG")) : 0;   // tuning switch
@@ -480,6 +496,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int st
   __syncthreads();
   const unsigned char* pb = reinterpret_cast<const unsigned char*>(patch);
   unsigned char* const wt = tr[wave];
+  float vmax = 0.f;
   for (int tile = 0; tile < CF_TILES; ++tile) {
   const int x0 = (sx * CF_TILES + tile) * 16;
   if (x0 >= p.W) break;                        // uniform: the strip runs past the image
@@ -521,6 +538,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int st
         for (int j = 0; j < 4; ++j) v[j] = fmaxf(acc[nt][rq * 4 + j] + bias[nt][rq][j], 0.f);
         const int piece = nt * 8 + 2 * rq + kgrp;
         *reinterpret_cast<f32x4*>(wt + (px * 16 + (piece ^ (px & 15))) * 16) = v;
+        if (p.usum) {                          // uniform; statistics of the fp32 tap as in conv_epilogue_t
+          f32x4 t = v;
+          unit_row_sum4(t);
+          const int sy = y0 + wave * 4 + mt * 2 + frag_py;
+          if (sy < p.H) {
+            vmax = fmaxf(fmaxf(vmax, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            if (frag_px == 0)
+              *reinterpret_cast<f32x4*>(p.usum + ((size_t)b * (p.H * (p.W >> 4)) + sy * (p.W >> 4) + (x0 >> 4)) * 64 + piece * 4) = t;
+          }
+        }
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -558,10 +585,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(ConvFirstArgs p, int st
     __syncthreads();
   }
   }
+  if (p.usum) umax_merge(p.umax + b * UMAX_SLOTS, (int)blockIdx.x * 4 + wave, vmax, lane);
 }
 
 int launch_conv_first(const ConvFirstArgs& a, hipStream_t s) {
   ARG_CHECK(a.H > 1 && a.W > 1 && a.B > 0);
+  ARG_CHECK(!a.usum || (a.y32 && a.umax && a.W % 16 == 0));
   const int strips_x = cdiv(a.W, 64), tiles_y = cdiv(a.H, 16);
   hipLaunchKernelGGL(conv_first_kernel, dim3(strips_x * tiles_y, a.B), dim3(256), 0, s, a, strips_x);
   HIP_TRY(hipGetLastError());

@@ -31,6 +31,8 @@ __device__ __host__ __forceinline__ bool skip_style_mat(int mat, int shared_styl
 struct StatArgs {
   const float* x[2];     // content base [P][Nc][C], style base [P][Ns][C]
   int n[2];
+  const float* u[2];     // per side: unit sums [P][ceil(n/16)][C] left by the conv epilogue that wrote x (ConvArgs::usum), or null
+  const unsigned* umax[2];   // with u: [P][UMAX_SLOTS] bit patterns whose maximum is the largest value of each map
   const float* mean;     // [2P][C] or null; if set, accumulate (x-mean)^2 instead of x
   float* partial;        // [2P][nslab][C]
   float* absmax;         // [2P][nslab] max |x| of the slab (first pass only) or null
@@ -38,33 +40,60 @@ struct StatArgs {
   int shared_style;
 };
 
+// First pass (mean == null): the sum runs over UNITS of 16 consecutive rows, each added up in the fixed tree of
+// unit_row_sum (common.h), then over the units of the slab in a fixed order.  A conv epilogue that wrote the features can
+// hand the unit sums over (u): the 8 GB pass over the features of a 32-pair step shrinks to a pass over 1/16 of them, and
+// the result is the same bit for bit whether the features come from the pipeline or from the caller (op-level entry
+// points, widths that are not a multiple of 16).
 __global__ __launch_bounds__(256) void colsum_kernel(StatArgs p) {
   __shared__ f32x4 red[256];
   const int mat = blockIdx.y, slab = blockIdx.x;
   if (skip_style_mat(mat, p.shared_style)) return;
   const int b = mat & 1, pair = mat >> 1;
   const int C = p.C, cq = C / 4;
-  const int nrp = 256 / cq;                  // rows handled in parallel (C <= 1024)
+  const int nrp = 256 / cq;                  // rows / units handled in parallel (C <= 1024)
   const int tid = threadIdx.x;
   const int rp = tid / cq, c4 = tid % cq;
   const int N = p.n[b];
-  const int rows_per_slab = (N + p.nslab - 1) / p.nslab;
-  const int r0 = slab * rows_per_slab;
-  const int r1 = min(N, r0 + rows_per_slab);
   const float* x = p.x[b] + (size_t)pair * N * C;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  f32x4 m = {0.f, 0.f, 0.f, 0.f};
   float amax = 0.f;
-  if (p.mean) m = *reinterpret_cast<const f32x4*>(p.mean + mat * C + c4 * 4);
-  if (rp < nrp) {
-    for (int r = r0 + rp; r < r1; r += nrp) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + c4 * 4);
-      if (p.mean) { v -= m; acc += v * v; }
-      else {
-        acc += v;
-        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  if (p.mean) {
+    const int rows_per_slab = (N + p.nslab - 1) / p.nslab;
+    const int r0 = slab * rows_per_slab;
+    const int r1 = min(N, r0 + rows_per_slab);
+    const f32x4 m = *reinterpret_cast<const f32x4*>(p.mean + mat * C + c4 * 4);
+    if (rp < nrp)
+      for (int r = r0 + rp; r < r1; r += nrp) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * C + c4 * 4);
+        v -= m; acc += v * v;
       }
-    }
+  } else {
+    const int units = (N + 15) >> 4;
+    const int ups = (units + p.nslab - 1) / p.nslab;
+    const int u0 = slab * ups, u1 = min(units, u0 + ups);
+    const float* U = p.u[b] ? p.u[b] + (size_t)pair * units * C : nullptr;
+    if (rp < nrp)
+      for (int u = u0 + rp; u < u1; u += nrp) {
+        if (U) {
+          acc += *reinterpret_cast<const f32x4*>(U + (size_t)u * C + c4 * 4);
+        } else {
+          f32x4 t[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int r = u * 16 + i;
+            t[i] = *reinterpret_cast<const f32x4*>(x + (size_t)min(r, N - 1) * C + c4 * 4);
+            if (r >= N) t[i] = f32x4{0.f, 0.f, 0.f, 0.f};            // ragged last unit: + 0 is exact
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(t[i][0]), fabsf(t[i][1]))), fmaxf(fabsf(t[i][2]), fabsf(t[i][3])));
+          }
+#pragma unroll
+          for (int w = 1; w < 16; w <<= 1)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2 * w) t[i] += t[i + w];
+          acc += t[0];
+        }
+      }
+    if (U) amax = __builtin_bit_cast(float, p.umax[b][pair * UMAX_SLOTS + (tid & (UMAX_SLOTS - 1))]);   // block max below
   }
   red[tid] = acc;
   __syncthreads();
@@ -2583,9 +2612,13 @@ size_t wct_workspace_bytes(int C, int Nc, int Ns, int P) {
 }
 
 static int launch_means(const float* content, int Nc, const float* style, int Ns, int C, int P,
-                        const WctCarve& w, bool with_var, int shared_style, hipStream_t s) {
+                        const WctCarve& w, bool with_var, int shared_style, hipStream_t s, const WctFeatStats* fs = nullptr) {
   StatArgs sa;
   sa.x[0] = content; sa.x[1] = style; sa.n[0] = Nc; sa.n[1] = Ns;
+  for (int b = 0; b < 2; ++b) {
+    sa.u[b] = fs && fs->umax[b] ? fs->u[b] : nullptr;
+    sa.umax[b] = sa.u[b] ? fs->umax[b] : nullptr;
+  }
   sa.mean = nullptr; sa.partial = w.stat_partial; sa.absmax = w.absmax; sa.C = C; sa.nslab = w.nslab; sa.shared_style = shared_style;
   hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
   hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.mean, C, w.nslab, (float)Nc, (float)Ns, shared_style);
@@ -2602,7 +2635,7 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
                half_t* out16, float* out32, void* workspace, size_t workspace_bytes, int* sweeps_dev,
                int stages, hipStream_t s, const hipStream_t* side, int nside, hipEvent_t ev_fork,
-               const hipEvent_t* ev_join, int shared_style, int* eig_fail) {
+               const hipEvent_t* ev_join, int shared_style, int* eig_fail, const WctFeatStats* stats) {
   ARG_CHECK(C % 32 == 0 && C >= 32 && C <= 1024 && Nc >= 2 && Ns >= 2 && P >= 1 && P <= 32);
   ARG_CHECK(mode == WCT_MODE_NP || mode == WCT_MODE_TF);
   // the covariance kernel addresses one feature map through a buffer resource with 32-bit byte offsets
@@ -2612,7 +2645,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   int rc;
   const size_t cc = (size_t)C * C;
   if (stages & WCT_STAGE_COV) {
-  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, false, shared_style, s))) return rc;
+  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, false, shared_style, s, stats))) return rc;
 
   // covariance partials: matrix 2p+side, side 0 = content, 1 = style; slices past a side's N write zeros
   const int BT = C >= 128 ? 128 : 64;
@@ -2735,12 +2768,13 @@ __global__ void adain_apply_kernel(const float* x, size_t n4_per_pair, int C, co
 }
 
 int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, float eps,
-                 half_t* out16, float* out32, void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style) {
+                 half_t* out16, float* out32, void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style,
+                 const WctFeatStats* stats) {
   ARG_CHECK(C % 4 == 0 && C <= 1024 && Nc >= 1 && Ns >= 1 && P >= 1 && P <= 32);
   WctCarve w = carve(workspace, C < 32 ? 32 : C, Nc, Ns, P);
   ARG_CHECK(workspace_bytes >= w.total);
   int rc;
-  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, true, shared_style, s))) return rc;
+  if ((rc = launch_means(content, Nc, style, Ns, C, P, w, true, shared_style, s, stats))) return rc;
   const size_t n4 = (size_t)Nc * C / 4;
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
