@@ -179,7 +179,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[N
 //  * __launch_bounds__(256, 2): two blocks resident per CU cover each other's chunk boundaries.
 // ---------------------------------------------------------------------------
 template <int TH, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
+__global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
   constexpr int PH = TH + 2;
   constexpr int MT = (TH / 2) / WM;
   constexpr int NT = (BN / 32) / WN;
@@ -405,6 +405,11 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   if (force == 2) return launch_conv_cfg<32, 64, 4, 1>(a, s);
   if (force == 3) return launch_conv_cfg<16, 64, 4, 1>(a, s);
   if (force == 4) return launch_conv_cfg<8, 64, 2, 2>(a, s);
+  // (round 3: a 256-pixel x 256-channel block, 4 x 4 MFMA tiles per wave with the accumulators in AGPRs, ONE wave per SIMD --
+  //  half the LDS fragment reads per MFMA.  As it stands it ties the 128-channel block: 512->512 @64 1156 vs 1136 TFLOP/s,
+  //  256->256 @128 1057 vs 1066, worse where the grid gets small (512->512 @32: 381 vs 590); without a partner block the
+  //  chunk boundaries, the first patch and the epilogue are exposed.  Kept as a switch: the starting point of DESIGN 8.2)
+  if (force == 5 && a.Cout % 256 == 0) return launch_conv_cfg<16, 256, 2, 2>(a, s);
   // (round 2: <32,64,2,2> and <16,128,1,4> -- the waves of a block split the output channels instead of the pixels,
   //  halving / removing the redundant weight streams -- measured 593 vs 601 TFLOP/s on 64->64 @512^2 and 5-8 % slower on
   //  the wide layers, profiles/r02_conv_cfg_sweep.txt: the weight streams are not what bounds these layers; removed)
