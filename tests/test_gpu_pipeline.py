@@ -723,3 +723,34 @@ def test_two_contexts_two_threads_and_no_memory_growth(weights):
     assert torch.cuda.mem_get_info()[0] == free0
     for c in ctxs:
         c.close()
+
+
+def test_epilogue_statistics_equal_the_pass_over_the_features(ctx, weights, tmp_path):
+    """The per-channel sums / maxima the transform needs come out of the conv epilogues that write the feature taps
+    (16-pixel unit sums, ConvArgs::usum; csrc/conv.hip) whenever the tap's width is a multiple of 16.  The frames must be
+    the ones the separate pass over the stored features gives (WCT_FUSE_STATS=0, read once per process: a subprocess), bit
+    for bit -- WCT and AdaIN, a batch, and a content whose deeper taps have widths that are not multiples of 16 (mixed)."""
+    import subprocess, sys
+    rng = np.random.default_rng(5)
+    cs = rng.integers(0, 256, (3, 160, 224, 3), dtype=np.uint8)        # tap widths 224, 112, 56, 28, 14: fused at the first two
+    st = rng.integers(0, 256, (128, 128, 3), dtype=np.uint8)           # 128, 64, 32, 16, 8: fused at four levels
+    np.savez(tmp_path / 'in.npz', cs=cs, st=st)
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from wct_tf_amd.context import Context\n"
+        "from wct_tf_amd.weights import synthetic_weights, RELU_TARGETS\n"
+        "d = np.load(%r)\n"
+        "c = Context(0); c.set_weights(synthetic_weights(seed=42))\n"
+        "a = c.stylize_batch(d['cs'], d['st'], RELU_TARGETS, alpha=0.8)\n"
+        "b = c.stylize_batch(d['cs'], d['st'], RELU_TARGETS, alpha=0.8, adain=True)\n"
+        "np.savez(%r, a=a, b=b)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / 'in.npz'),
+                                       str(tmp_path / 'out.npz')))
+    env = dict(os.environ, WCT_FUSE_STATS='0')
+    subprocess.run([sys.executable, '-c', script], check=True, env=env, timeout=600)
+    ref = np.load(tmp_path / 'out.npz')
+    got_wct = ctx.stylize_batch(cs, st, RELU_TARGETS, alpha=0.8)
+    got_adain = ctx.stylize_batch(cs, st, RELU_TARGETS, alpha=0.8, adain=True)
+    assert np.array_equal(got_wct, ref['a'])
+    assert np.array_equal(got_adain, ref['b'])
+    assert len({f.tobytes() for f in got_wct}) == 3
