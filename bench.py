@@ -364,7 +364,7 @@ def main():
                 'traffic_unit': 'HBM bytes per launch; NOT measured in this run: the committed rocprofv3 PMC passes of this '
                                 'workload (%s)' % traffic_src if traffic else 'no committed PMC pass for this batch/size',
                 'algorithmic_bytes_per_launch': conv['bytes'] / max(1, conv['launches']),
-                'kernel': 'conv3x3_mfma_kernel (all launches of the class: the largest time class of the step)',
+                'kernel': 'conv3x3_mfma_kernel (all launches of the class: the largest time class of the step; the tap launches -- 8 of 65 per step -- also take the transform\'s per-channel sums and maxima in their epilogue)',
                 'launches': conv['launches'], 'avg_launch_ms': conv['ms'] / max(1, conv['launches']),
                 'algorithmic_flops_per_frame': conv_flops_per_frame(S),
                 'algorithmic_gbytes_per_s': conv['bytes'] / (conv['ms'] * 1e-3) / 1e9 if conv['ms'] > 0 else 0.0,
