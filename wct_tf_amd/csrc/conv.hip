@@ -186,8 +186,13 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   constexpr int PATCH_ITEMS = PH * 18 * 4;
   constexpr int PATCH_PER_THREAD = (PATCH_ITEMS + 255) / 256;
   constexpr int PATCH_BYTES = PH * PITCH * 64;
-  constexpr int DUMP_OFF = PATCH_BYTES;
-  constexpr int BIAS_OFF = PATCH_BYTES + 4096;
+  // one wave per SIMD (the 4 x 4-tile block) has no partner block to cover a chunk boundary: its patch is double-buffered --
+  // the next chunk's patch is parked in the other buffer under the last tap's MFMAs, and the boundary is ONE barrier
+  constexpr bool DB = MT * NT > 8;
+  constexpr int NBUF = DB ? 2 : 1;
+  constexpr int DUMP_OFF = PATCH_BYTES;          // a buffer = patch + the dump slots of the idle loader lanes
+  constexpr int BUF_STRIDE = PATCH_BYTES + 4096;
+  constexpr int BIAS_OFF = NBUF * BUF_STRIDE;
   // tap at which the next K-chunk's patch loads are issued (their registers are live from there to the
   // chunk boundary only); the tall tile has no registers to spare and loads at the boundary
   constexpr int PF_TAP = TH <= 16 ? 6 : 9;
@@ -272,10 +277,10 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   half8 wf[2][NT][2];                        // ping-pong weight fragments, loaded a full tap ahead
   half8 bf[2][MT];                           // ping-pong pixel fragments, read one k-step (8 MFMAs) ahead
 
-  auto read_group = [&](half8 (&dst)[MT], int ky, int kx, int ks) {
+  auto read_group = [&](half8 (&dst)[MT], int ky, int kx, int ks, int buf) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-      dst[mt] = *reinterpret_cast<const half8*>(patch_lds + rd_base[kx][ks] + (mt * 2 + ky) * PITCH * 64);
+      dst[mt] = *reinterpret_cast<const half8*>(patch_lds + rd_base[kx][ks] + (mt * 2 + ky) * PITCH * 64 + buf * BUF_STRIDE);
   };
   auto mma_group = [&](half8 (&w)[NT][2], half8 (&bq)[MT], int ks) {
 #pragma unroll
@@ -289,10 +294,10 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
     for (int i = 0; i < PATCH_PER_THREAD; ++i)
       patch_regs[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, patch_src[i], chunk * BK * 2, 0);
   };
-  auto store_patch = [&]() {
+  auto store_patch = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < PATCH_PER_THREAD; ++i)
-      *reinterpret_cast<u32x4*>(smem + patch_dst[i]) = patch_regs[i];
+      *reinterpret_cast<u32x4*>(smem + patch_dst[i] + buf * BUF_STRIDE) = patch_regs[i];
   };
 
   TS(1);
@@ -302,10 +307,10 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
       wf[0][nt][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wfrag[nt] + ks * 1024, 0, 0));
-  store_patch();
+  store_patch(0);
   __syncthreads();
   TS(2);
-  read_group(bf[0], 0, 0, 0);
+  read_group(bf[0], 0, 0, 0, 0);
 
 #pragma unroll 1
   for (int pair = 0; pair < n_chunks; pair += 2) {
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
       const int ky = tap / 3, kx = tap % 3;
       const int ntap = (tap + 1) % 9, nky = ntap / 3, nkx = ntap % 3;
       const bool more = chunk_i + 1 < n_chunks;
+      const int buf = DB ? t / 9 : 0;            // compile-time: an immediate in the fragment reads
       // 1) next tap's weight fragments (past the very end: re-read, unused); the next patch leaves PF_TAP early
       {
         const int nchunk = tap == 8 ? (more ? chunk_i + 1 : chunk_i) : chunk_i;
@@ -328,25 +334,28 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
       }
       if (tap == PF_TAP && more) load_patch(chunk_i + 1);
       // 2) second k-step's pixels go out, first k-step's MFMAs run on fragments read during the previous tap
-      read_group(bf[1], ky, kx, 1);
+      read_group(bf[1], ky, kx, 1, buf);
+      if (DB && tap == 8 && more) store_patch(buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mma_group(wf[t & 1], bf[0], 0);
       __builtin_amdgcn_sched_barrier(0);
       // 3) next tap's first k-step goes out under the second k-step's MFMAs; at a chunk boundary the
       //    patch is replaced first (every wave done reading it)
       if (tap != 8) {
-        read_group(bf[0], nky, nkx, 0);
+        read_group(bf[0], nky, nkx, 0, buf);
         __builtin_amdgcn_sched_barrier(0);
         mma_group(wf[t & 1], bf[1], 1);
       } else {
         mma_group(wf[t & 1], bf[1], 1);
         if (more) {
           __syncthreads();
-          if (PF_TAP > 8) load_patch(chunk_i + 1);
-          store_patch();
-          __syncthreads();
+          if (!DB) {
+            if (PF_TAP > 8) load_patch(chunk_i + 1);
+            store_patch(0);
+            __syncthreads();
+          }
         }
-        read_group(bf[0], 0, 0, 0);
+        read_group(bf[0], 0, 0, 0, DB ? buf ^ 1 : 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -365,7 +374,8 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
   const int n_tiles = a.Cout / BN;
   constexpr int PH = TH + 2;
-  const size_t lds = (size_t)PH * PITCH * 64 + 4096 + BN * sizeof(float);     // patch, dump slots, bias
+  constexpr int NBUF = ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 2 : 1;
+  const size_t lds = (size_t)NBUF * (PH * PITCH * 64 + 4096) + BN * sizeof(float);     // NBUF x (patch, dump slots), bias
   dim3 grid(tiles_x * tiles_y * n_tiles, a.B);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
 #ifdef CONV_TS
@@ -406,9 +416,10 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   if (force == 3) return launch_conv_cfg<16, 64, 4, 1>(a, s);
   if (force == 4) return launch_conv_cfg<8, 64, 2, 2>(a, s);
   // (round 3: a 256-pixel x 256-channel block, 4 x 4 MFMA tiles per wave with the accumulators in AGPRs, ONE wave per SIMD --
-  //  half the LDS fragment reads per MFMA.  As it stands it ties the 128-channel block: 512->512 @64 1156 vs 1136 TFLOP/s,
-  //  256->256 @128 1057 vs 1066, worse where the grid gets small (512->512 @32: 381 vs 590); without a partner block the
-  //  chunk boundaries, the first patch and the epilogue are exposed.  Kept as a switch: the starting point of DESIGN 8.2)
+  //  half the LDS fragment reads per MFMA.  As it stands it ties the 128-channel block: 512->512 @64 1156 vs 1136 TFLOP/s
+  //  (1175 vs 1143 with the double-buffered patch, DB), 256->256 @128 1057-1068 vs 1066-1085, worse where the grid gets
+  //  small (512->512 @32: 381 vs 590); without a partner block the first patch and the epilogue of every tile are exposed.
+  //  Kept as a switch: the starting point of DESIGN 8.2)
   if (force == 5 && a.Cout % 256 == 0) return launch_conv_cfg<16, 256, 2, 2>(a, s);
   // (round 2: <32,64,2,2> and <16,128,1,4> -- the waves of a block split the output channels instead of the pixels,
   //  halving / removing the redundant weight streams -- measured 593 vs 601 TFLOP/s on 64->64 @512^2 and 5-8 % slower on
