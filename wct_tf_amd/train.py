@@ -225,53 +225,46 @@ def train(argv=None):
     class StepFailed(Exception):
         """a step every rank agreed to abandon (recoverable: reload the latest checkpoint everywhere)"""
 
-    def agree(ok, err):
-        """data parallel: True only if EVERY rank's local phase succeeded; all ranks raise together otherwise"""
-        if dist is None:
-            if not ok:
-                raise StepFailed(str(err))
-            return
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
-                            device='cuda:%d' % args.device if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+    def agree(res, err):
+        """data parallel: ONE small all-reduce per step carries the four losses and a failure flag (round 3; the separate
+        agreement collective + host sync of round 2 is gone).  Returns the losses averaged over the ranks; every rank
+        raises StepFailed together if the local phase failed anywhere -- before the gradients are exchanged."""
+        vals = [res['feature_loss'], res['pixel_loss'], res['tv_loss'], res['total_loss']] if res is not None else [0.0] * 4
+        t = torch.tensor(vals + [0.0 if err is None else 1.0], dtype=torch.float64,
+                         device='cuda:%d' % args.device if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t.tolist()
+        if t[4] > 0:
             raise StepFailed(str(err) if err is not None else 'another rank failed this step')
+        return {'feature_loss': t[0] / world, 'pixel_loss': t[1] / world, 'tv_loss': t[2] / world, 'total_loss': t[3] / world}
 
     def one_step(x, step, lr):
         """single GPU: one fused call; data parallel: gradients, one all-reduce (average), the same Adam everywhere.
         `step` is the optimiser's own step count (Adam bias correction), see the module docstring."""
         if dist is None:
             try:
-                res = ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
-                                     pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+                return ctx.train_step(relu, x, step=step, learning_rate=lr, feature_weight=args.feature_weight,
+                                      pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
             except Exception as e:                  # noqa: BLE001
                 raise StepFailed(str(e))
-        else:
-            res, err = None, None
-            try:                                    # local phase: may fail on one rank only
-                res = ctx.train_step(relu, x, step=step, learning_rate=0.0, feature_weight=args.feature_weight,
-                                     pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
-            except Exception as e:                  # noqa: BLE001
-                err = e
-            agree(err is None, err)
-            if lr == 0.0:
-                pass                                # evaluation only (validation batch): no update
-            elif dist.get_backend() == 'nccl':
-                dist.all_reduce(grad[0], op=dist.ReduceOp.SUM)
-                grad[0].div_(world)
-            else:                                   # host-staged dry run
-                host = grad[0].cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                grad[0].copy_(host / world)
-            if lr != 0.0:
-                torch.cuda.synchronize()
-                ctx.train_apply(relu, step, lr)     # collective phase: an exception here ends the job (not caught below)
-        if dist is not None:
-            t = torch.tensor([res['feature_loss'], res['pixel_loss'], res['tv_loss'], res['total_loss']], dtype=torch.float64,
-                             device='cuda:%d' % args.device if dist.get_backend() == 'nccl' else 'cpu')
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t = (t / world).tolist()
-            res = {'feature_loss': t[0], 'pixel_loss': t[1], 'tv_loss': t[2], 'total_loss': t[3]}
+        res, err = None, None
+        try:                                        # local phase: may fail on one rank only
+            res = ctx.train_step(relu, x, step=step, learning_rate=0.0, feature_weight=args.feature_weight,
+                                 pixel_weight=args.pixel_weight, tv_weight=args.tv_weight)
+        except Exception as e:                      # noqa: BLE001
+            err = e
+        res = agree(res, err)
+        if lr == 0.0:
+            return res                              # evaluation only (validation batch): no update
+        if dist.get_backend() == 'nccl':
+            dist.all_reduce(grad[0], op=dist.ReduceOp.SUM)
+            grad[0].div_(world)
+        else:                                       # host-staged dry run
+            host = grad[0].cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            grad[0].copy_(host / world)
+        torch.cuda.synchronize()
+        ctx.train_apply(relu, step, lr)             # collective phase: an exception here ends the job (not caught below)
         return res
 
     step = step0
