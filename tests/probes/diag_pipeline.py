@@ -1,6 +1,6 @@
 """Free-running, level-by-level comparison of the GPU ops with the oracle (debug aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from wct_tf_amd import _lib

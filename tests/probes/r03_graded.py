@@ -1,7 +1,7 @@
 """WCT path on hard spectra at C = 512: graded covariances (eigenvalues over 5-7 decades) at N = 4096 and N = 256 < C,
 sweeps used per matrix, time, and error against the NumPy oracle (wct_np semantics)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import oracle
 from wct_tf_amd import _lib

@@ -1,10 +1,10 @@
 """Accuracy of the transform on the teacher-forced level features of a 512x512 five-level frame, as a function of the
 eigensolver's convergence tolerance (WCT_JACOBI_CONV_TOL, read once per process): prints rel. error vs the oracle and
-the sweeps used, per level.  usage: python tools/wct_tol_probe.py [cache.npz]"""
+the sweeps used, per level.  usage: python tests/probes/wct_tol_probe.py [cache.npz]"""
 import os
 import sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import oracle
 from wct_tf_amd import _lib
 from wct_tf_amd.context import Context

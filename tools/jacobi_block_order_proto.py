@@ -97,7 +97,7 @@ def run(A0, mode, tol=1.5e-2, max_steps=150):
                 break
     print('%-8s outer steps %3d (= %.1f sweeps of %d)  %s' % (mode, steps, steps / (nblk - 1.0), nblk - 1, ' '.join(hist)), flush=True)
 
-z = np.load(sys.argv[1] if len(sys.argv) > 1 else '/tmp/wct_levels.npz')     # cache written by tools/wct_tol_probe.py
+z = np.load(sys.argv[1] if len(sys.argv) > 1 else '/tmp/wct_levels.npz')     # cache written by tests/probes/wct_tol_probe.py
 for i, side in ((1, 'fc'), (0, 'fc'), (2, 'fs')):
     f = z['%s%d' % (side, i)]
     C = f.shape[-1]

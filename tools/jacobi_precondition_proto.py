@@ -87,7 +87,7 @@ def pivoted_cholesky(A):
     return L, perm
 
 if __name__ == '__main__':
-    z = np.load(sys.argv[1] if len(sys.argv) > 1 else "/tmp/wct_levels.npz")     # level features: tools/wct_tol_probe.py writes this cache
+    z = np.load(sys.argv[1] if len(sys.argv) > 1 else "/tmp/wct_levels.npz")     # level features: tests/probes/wct_tol_probe.py writes this cache
     for i in (0, 1, 2):
         for side in ('fc', 'fs'):
             f = z['%s%d' % (side, i)]
