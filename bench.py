@@ -200,17 +200,20 @@ def main():
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the stylize path has no CPU fallback')
+    from wct_tf_amd.dist import resolve_world, launch_ranks
     # dry-run switches for a box with fewer GPUs than ranks (the control flow of the N > 1 path without RCCL):
     # WCT_BENCH_BACKEND=gloo stages the exchange through the host, WCT_BENCH_SHARE_GPU=1 wraps ranks onto the GPUs
     backend = os.environ.get('WCT_BENCH_BACKEND', 'nccl')
-    if os.environ.get('WCT_BENCH_SHARE_GPU'):
+    share_gpu = bool(os.environ.get('WCT_BENCH_SHARE_GPU'))
+    # --gpus N always means N ranks: a launcher's WORLD_SIZE must agree, and without a launcher this process starts them
+    # itself (never a silent single-rank run under an n_gpus = N label)
+    role = resolve_world(args.gpus, share_gpu=share_gpu)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the stylize path has no CPU fallback')
+    if role[0] == 'launch':
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], script=os.path.abspath(__file__)))
+    _, rank, world, local_rank = role
+    if share_gpu:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:

@@ -4,8 +4,61 @@ sharded statically, ONE exchange step -- a gather of the finished uint8 frames t
 
 The reference has no multi-device code at all (single device string, wct.py:17,31); units
 are the (content, style) pairs it already processes one at a time (stylize.py:70-100)."""
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def resolve_world(n_gpus, environ=None, share_gpu=False, device_count=None):
+    """What `--gpus N` means for this process.  Returns ('launch', N) when N > 1 ranks still have to be started (no
+    launcher in the environment: the caller re-executes itself under launch_ranks), or ('rank', rank, world, local_rank)
+    when this process IS a rank (N = 1, or a launcher set WORLD_SIZE).  Exits non-zero -- never runs fewer ranks than
+    asked for -- when the launcher's WORLD_SIZE differs from N, or when N exceeds the GPUs present and ranks may not
+    share one (`share_gpu`: dry runs only)."""
+    env = os.environ if environ is None else environ
+    if n_gpus < 1:
+        raise SystemExit('--gpus %d: need at least one GPU' % n_gpus)
+    if 'WORLD_SIZE' in env:
+        world = int(env['WORLD_SIZE'])
+        if world != n_gpus:
+            raise SystemExit('--gpus %d but the launcher set WORLD_SIZE=%d: refusing to run a different number of ranks' % (n_gpus, world))
+    if device_count is None:
+        device_count = torch.cuda.device_count()
+    if n_gpus > device_count and not share_gpu:
+        raise SystemExit('--gpus %d but %d GPU(s) visible (WCT_BENCH_SHARE_GPU=1 wraps ranks onto the GPUs for dry runs)' % (n_gpus, device_count))
+    if 'WORLD_SIZE' in env:
+        rank = int(env.get('RANK', '0'))
+        return ('rank', rank, n_gpus, int(env.get('LOCAL_RANK', str(rank))))
+    if n_gpus == 1:
+        return ('rank', 0, 1, 0)
+    return ('launch', n_gpus)
+
+
+def launch_ranks(n_gpus, argv, script=None, module=None, timeout=None):
+    """Start N ranks of this program on ONE node, one per GPU, and wait for them: `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> <script | -m module> argv` -- the same
+    command line the driver uses, so a self-launched run and a torchrun-launched run are the same job.  stdout/stderr pass
+    through (rank 0 prints the result).  Returns the launcher's exit code."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port())]
+    cmd += ['-m', module] if module else [script]
+    cmd += list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env, timeout=timeout)
 
 
 def shard_range(n_items, world_size, rank):

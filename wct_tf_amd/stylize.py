@@ -2,7 +2,7 @@
 MI355X path.  Flag names, defaults and the output naming `{content}_{style}{ext}` are the reference's; `--checkpoints`
 takes TF checkpoint directories or .npz files (see wct.py), `--vgg-path` the .t7 or a .npz, and
 `--synthetic-weights SEED` stands in when neither exists.  Under torchrun each rank takes a shard of the content
-files (rank_shard)."""
+files (rank_shard); `--gpus N` without a launcher starts the N ranks itself."""
 import argparse
 import os
 import time
@@ -36,6 +36,9 @@ _FLAGS = [
     (('--ss-stride',), dict(type=int, default=1, help='style-swap stride')),
     (('--synthetic-weights',), dict(type=int, default=None, metavar='SEED', help='seeded synthetic weights instead of files')),
     (('--wct-mode',), dict(choices=['tf', 'np'], default='tf', help='wct_tf (the graph) or wct_np semantics')),
+    (('--gpus',), dict(type=int, default=0, metavar='N',
+                       help='shard the content files over N GPUs of this node, one process per GPU: started here when no '
+                            'launcher did (0: whatever the launcher set, else one GPU)')),
 ]
 
 
@@ -56,7 +59,11 @@ def rank_shard(items, environ=None):
         return list(items), None
     from .dist import shard_range
     lo, hi = shard_range(len(items), world, rank)
-    return list(items)[lo:hi], '/gpu:%d' % int(env.get('LOCAL_RANK', str(rank)))
+    local = int(env.get('LOCAL_RANK', str(rank)))
+    if env.get('WCT_BENCH_SHARE_GPU'):                       # dry run on a box with fewer GPUs than ranks
+        import torch
+        local %= max(1, torch.cuda.device_count())
+    return list(items)[lo:hi], '/gpu:%d' % local
 
 
 def _listing(path):
@@ -96,6 +103,16 @@ def main(argv=None):
     args = parser.parse_args(argv)
     if args.synthetic_weights is None and not args.checkpoints:
         parser.error('--checkpoints is required (stylize.py:17) unless --synthetic-weights SEED is given')
+    if args.gpus > 0:
+        # --gpus N means N ranks: agree with a launcher's WORLD_SIZE, or start the ranks from here (dist.resolve_world)
+        from .dist import resolve_world, launch_ranks
+        import sys
+        role = resolve_world(args.gpus, share_gpu=bool(os.environ.get('WCT_BENCH_SHARE_GPU')))
+        if role[0] == 'launch':
+            rc = launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv), module='wct_tf_amd.stylize')
+            if rc:
+                raise SystemExit(rc)
+            return None
     t0 = time.time()
     weights = None
     if args.synthetic_weights is not None:
