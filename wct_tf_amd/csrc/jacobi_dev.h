@@ -1,0 +1,764 @@
+// Device-side pieces of the batched block-Jacobi eigensolver (K5) that are shared by the kernels of wct.hip and by the
+// CPU lane-emulation test (tests/emul): the solver's state words, the pairing schedule, the rotation, the generic
+// LDS-image rotation sets, the argument block of the look-ahead launches and the round-4 register-resident pair problem
+// (namespace r4).  Device code only: nothing here touches the HIP runtime API.  The includer provides the vector typedefs
+// of common.h (wct.hip includes that first; the emulation brings its own prelude, tests/emul/hip_emul.h).
+#pragma once
+#include <type_traits>
+#include <utility>
+
+struct JacobiState {
+  unsigned int offmax;   // max |a_pq|/sqrt(a_pp a_qq) over the pairs rotated this sweep (float bits)
+  int done;              // 0 rotating, 1 converged, 2 failed: non-finite input
+  int sweeps;
+  unsigned int offsig;   // the same maximum over the SIGNIFICANT pairs only (a diagonal above `floor`)
+  float floor;           // 1e-4 max|a_ii| of the previous sweep (-> 1e-4 lambda_max): diagonals below it are taken to belong
+                         // to the numerical null space of a matrix of this norm (~1700 eps ||A||) when the STATUS is judged
+  unsigned int last_sig; // offsig of the last completed sweep (what jacobi_finalize_kernel judges)
+  unsigned int dmax;     // max |a_ii| seen by this sweep's pair problems (float bits)
+  float r2;              // strict residual measure of the last completed sweep (jacobi_resid_kernel), -1 before the first
+  float r2l;             // the lenient one (what the final status is judged by)
+  int pad;               // look-ahead path: the buffer (0: A, 1: the second one) that held the matrix when it was declared done
+  int seg_stop;          // number of launch segments whose rotations belong to this matrix (INT_MAX while it is still rotating)
+  int pad2;
+};
+constexpr int JACOBI_RESID_CHUNKS = 16;
+constexpr float JACOBI_SIG_FLOOR = 1e-4f;
+
+__device__ __forceinline__ int rr_idx(int pos, int step, int n) {
+  // circle method: position 0 is fixed, the other n-1 rotate
+  if (pos == 0) return 0;
+  int v = pos - 1 + step;
+  if (v >= n - 1) v -= n - 1;
+  return v + 1;
+}
+
+// blocks (bi, bj) of pair g at outer step `step`; step < 0 is the intra step: neighbours (2g, 2g+1)
+__device__ __forceinline__ void block_pair(int g, int step, int nblk, int& bi, int& bj) {
+  if (step < 0) { bi = 2 * g; bj = 2 * g + 1; }
+  else { bi = rr_idx(g, step, nblk); bj = rr_idx(nblk - 1 - g, step, nblk); }
+}
+
+template <int B>
+__device__ __forceinline__ int pair_index(int r, int bi, int bj) {
+  return r < B ? bi * B + r : bj * B + (r - B);
+}
+
+constexpr float JACOBI_ROT_TOL = 1e-6f;    // skip rotations below this relative size
+constexpr float JACOBI_CONV_TOL = 1e-2f;   // a sweep that never saw more than this is the last one (quadratic convergence;
+                                           // measured: WCT error vs the oracle identical for 2e-3 and 1e-2, 100x worse at 5e-2)
+constexpr float JACOBI_FLOOR = 1e-6f;      // both diagonals below this: the pair cannot reach the 1e-5 cut-off
+
+// rotation (c, s) that annihilates a_pq; `off` = pre-rotation relative size (0 if skipped).
+// t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (a_qq - a_pp) / (2 a_pq), written as
+// t = +-|a_pq| / (|tau| + sqrt(tau^2 + a_pq^2)), tau = (a_qq - a_pp)/2: three transcendentals
+// on the dependent chain (sqrt, rcp, rsq) and no division by a_pq.
+// `sig` = the same measure if the pair is significant (its larger diagonal is above the matrix' noise floor), else 0:
+// pairs inside the numerical null space keep relative off-diagonals of O(1) for ever (every update regenerates
+// rounding noise there) without mattering for f(A); they are still rotated, but they do not count as "not converged".
+// The same in two parts for the pivot wave of jacobi_cross_sets_pw: the rotation itself is on the serial chain of a set
+// (it gates every other wave at the barrier), the convergence statistics are not -- they are evaluated after (c, s) has
+// been published, under the latency of that LDS write.
+__device__ __forceinline__ bool jacobi_rotation_cs(float app, float aqq, float apq, float& c, float& s) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
+  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
+  const float tau = 0.5f * (aqq - app);
+  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
+  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
+  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
+  const float n2 = 1.f + t * t;
+  float r = __builtin_amdgcn_rsqf(n2);
+  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
+  c = rot ? r : 1.f;
+  s = rot ? r * t : 0.f;
+  return rot;
+}
+__device__ __forceinline__ void jacobi_rotation_stats(float app, float aqq, float apq, float floor_m, bool rot, float& off, float& sig) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  const float rel = den2 > 0.f ? fminf(aapq * __builtin_amdgcn_rsqf(den2), 1.f) : 1.f;
+  off = rot ? rel : 0.f;
+  // branch-free (selects, not exec-mask branches: the pivot wave is the pole of every set)
+  const float mixed = fmaxf(aapq * __builtin_amdgcn_rcpf(big), small < 1e-5f ? 0.1f * aapq * __builtin_amdgcn_rsqf(big * 1e-5f) : 0.f);
+  const float sig_mixed = big > floor_m ? fminf(off, mixed) : 0.f;
+  sig = small > floor_m ? off : sig_mixed;
+}
+
+__device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq, float floor_m, float& c, float& s, float& off, float& sig) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  // (a) both diagonals far below the 1e-5 cut-off: whatever they mix stays dropped;
+  // (b) coupling of a kept direction into a noise-level one with a negligible angle
+  // bitwise & / | on the predicates: && would become an exec-mask branch around the second half
+  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
+  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
+  const float rel = den2 > 0.f ? fminf(aapq * __builtin_amdgcn_rsqf(den2), 1.f) : 1.f;
+  const float tau = 0.5f * (aqq - app);
+  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
+  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
+  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
+  const float n2 = 1.f + t * t;
+  float r = __builtin_amdgcn_rsqf(n2);
+  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
+  c = rot ? r : 1.f;
+  s = rot ? r * t : 0.f;
+  off = rot ? rel : 0.f;
+  // both diagonals significant: the cosine; one significant, the other inside the rounding noise (a cosine against
+  // it cannot settle): the rotation angle a_pq / big, and -- if the small one is below the reference's 1e-5 cut-off --
+  // that it stays there: contamination a_pq^2 / big below 1 % of the cut-off; none significant: does not count
+  const float mixed = fmaxf(aapq * __builtin_amdgcn_rcpf(big), small < 1e-5f ? 0.1f * aapq * __builtin_amdgcn_rsqf(big * 1e-5f) : 0.f);
+  sig = small > floor_m ? off : (big > floor_m ? fminf(off, mixed) : 0.f);
+}
+
+// Rotation sets on an N x N symmetric pair problem (N = 32 or 64: blocks I = 0..N/2-1 and
+// J = N/2..N-1) held in LDS, by (N/2)^2 threads t = (k, l), N/2 disjoint pairs per set.
+// S and the accumulated rotations Q are interleaved as float2 {S[r][c], Q[r][c]} so thread
+// (k, l) moves its 2x2 block of both with four 8-byte LDS reads and writes (rows {p_k, q_k} x
+// columns {p_l, q_l}).  Two LDS images ping-pong, so a rotation set costs ONE barrier.  Each
+// thread derives rotation(l) from three more reads; rotation(k) is fetched from the lane of
+// its own wave that has l == k (ds_bpermute: no LDS round trip, no serial section).
+//   SWEEP_CROSS  the (N/2)^2 pairs (i in I, j in J), N/2 sets     -- one outer step
+//   SWEEP_INTRA  the pairs inside I and inside J, N/2-1 sets      -- once per outer sweep
+// so that one outer sweep visits every pair of the C indices exactly once (a true cyclic
+// Jacobi sweep).  All threads of the block call this together (contains __syncthreads()).
+// Returns the index of the image that holds the result.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+enum { SWEEP_CROSS = 1, SWEEP_INTRA = 2 };
+template <int MODE, int N>
+__device__ __forceinline__ void sweep_pair(int j, int s, int& p, int& q) {
+  constexpr int NP = N / 2;
+  if (MODE == SWEEP_CROSS) { p = j; q = NP + ((j + s) & (NP - 1)); }
+  else { const int base = j & (NP / 2) ? NP : 0, jj = j & (NP / 2 - 1); p = base + rr_idx(jj, s, NP); q = base + rr_idx(NP - 1 - jj, s, NP); }
+}
+//
+// In CROSS mode the three values every thread needs for rotation(l) -- S[p][p], S[q][q], S[p][q] --
+// are mirrored in two small compact arrays (DO: diagonal D[2][N] and pair elements O[2][N/2]), kept
+// current by the threads that own them; reading them straight out of the float2 image costs three
+// 4-way bank-conflicted loads per thread and set (the diagonal has stride 2(N+2) dwords).
+// KB = 2x2 blocks per thread (rows k, k + NP/KB, ...; one column pair l): rotation(l) is derived once
+// per thread and reused for its KB blocks.
+template <int MODE, int N, int KB>
+__device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float floor_m, float& my_off, float& my_sig) {
+  constexpr int NP = N / 2, PITCH = N + 1, IMG = N * PITCH, KS = NP / KB;
+  constexpr int NSETS = MODE == SWEEP_CROSS ? NP : NP - 1;
+  const int kq = t / NP, l = t % NP;
+  float* const Dg = DO;                          // [2][N]
+  float* const Og = DO + 2 * N;                  // [2][NP]
+  if (MODE == SWEEP_CROSS) {
+    for (int i = t; i < N; i += NP * KS) Dg[i] = SQ[i * PITCH + i][0];
+    for (int i = t; i < NP; i += NP * KS) Og[i] = SQ[i * PITCH + NP + i][0];      // set 0 pairs j with NP + j
+    __syncthreads();
+  }
+  int cur = 0;
+  for (int s = 0; s < NSETS; ++s) {
+    int pl, ql;
+    sweep_pair<MODE, N>(l, s, pl, ql);
+    const f32x2* C0 = SQ + cur * IMG;
+    f32x2* N0 = SQ + (cur ^ 1) * IMG;
+    // every LDS read of the set is issued before anything depends on it
+    float lpp, lqq, lpq;
+    if (MODE == SWEEP_CROSS) { lpp = Dg[cur * N + pl]; lqq = Dg[cur * N + ql]; lpq = Og[cur * NP + l]; }
+    else { lpp = C0[pl * PITCH + pl][0]; lqq = C0[ql * PITCH + ql][0]; lpq = C0[pl * PITCH + ql][0]; }
+    int pk[KB], qk[KB];
+    f32x2 app[KB], apq[KB], aqp[KB], aqq[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      sweep_pair<MODE, N>(kq + i * KS, s, pk[i], qk[i]);
+      app[i] = C0[pk[i] * PITCH + pl]; apq[i] = C0[pk[i] * PITCH + ql];
+      aqp[i] = C0[qk[i] * PITCH + pl]; aqq[i] = C0[qk[i] * PITCH + ql];
+    }
+    float cl, sl, offl, sigl;
+    jacobi_rotation(lpp, lqq, lpq, floor_m, cl, sl, offl, sigl);
+    my_off = fmaxf(my_off, offl);
+    my_sig = fmaxf(my_sig, sigl);
+    const int nx = cur ^ 1;
+#pragma unroll
+    for (int i = 0; i < KB; ++i) {
+      const int k = kq + i * KS;
+      const int src_lane = (t & (64 - NP)) | k;      // lane of my wave whose l equals this k
+      const float ck = __shfl(cl, src_lane, 64), sk = __shfl(sl, src_lane, 64);
+      // S: columns (pair l), then rows (pair k);  Q: columns only
+      const float ypp = cl * app[i][0] - sl * apq[i][0], ypq = sl * app[i][0] + cl * apq[i][0];
+      const float yqp = cl * aqp[i][0] - sl * aqq[i][0], yqq = sl * aqp[i][0] + cl * aqq[i][0];
+      f32x2 npp, npq, nqp, nqq;
+      npp[0] = ck * ypp - sk * yqp;  npq[0] = ck * ypq - sk * yqq;
+      nqp[0] = sk * ypp + ck * yqp;  nqq[0] = sk * ypq + ck * yqq;
+      npp[1] = cl * app[i][1] - sl * apq[i][1];  npq[1] = sl * app[i][1] + cl * apq[i][1];
+      nqp[1] = cl * aqp[i][1] - sl * aqq[i][1];  nqq[1] = sl * aqp[i][1] + cl * aqq[i][1];
+      N0[pk[i] * PITCH + pl] = npp;  N0[pk[i] * PITCH + ql] = npq;
+      N0[qk[i] * PITCH + pl] = nqp;  N0[qk[i] * PITCH + ql] = nqq;
+      if (MODE == SWEEP_CROSS) {
+        if (k == l) { Dg[nx * N + pk[i]] = npp[0]; Dg[nx * N + qk[i]] = nqq[0]; }
+        if (l == ((k + 1) & (NP - 1))) Og[nx * NP + k] = npq[0];     // S[p_k][q_k] of the next set
+      }
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  return cur;
+}
+
+struct JacobiFusedArgs {
+  const float* Pr;      // [nmat][C][C] state the U part reads and the D part takes its look-ahead block from
+  float* Pw;            // [nmat][C][C] state the U part writes
+  float* V;             // [nmat][C][C] eigenvector accumulation, in place
+  const float* Qr; const float* Sr;   // [nmat][npair][M2*M2] rotations / rotated pair problems of step_u
+  float* Qw; float* Sw;               // ... written by the D part (step_d)
+  const half_t* Qr16; half_t* Qw16;   // the same rotations split into fp16 hi + lo MFMA fragments (V <- V Q; see qfrag16)
+  JacobiState* st;
+  int C, nmat;
+  int step_d, step_u;   // outer step of the pair problems / of the tile update (= the step before step_d)
+  int has_d, has_u;
+  int first;            // the D part loads its pair problems straight from Pr (nothing is pending on it)
+  int with_v;           // the U part also updates V (otherwise jacobi_vstrip_kernel applies the segment's rotations later)
+  int dbg;              // timing experiments (WCT_JACOBI_DBG): 1 U blocks exit at once, 2 D blocks exit at once, 4 no rotation sets
+};
+
+// Rotation matrices are stored in FRAGMENT order (the A operand of v_mfma_f32_16x16x4_f32 for V Q, see
+// jacobi_vstrip_kernel): float4 f = (mt * (M2/16) + t) * 64 + lane holds Q[16 t + 4 (lane >> 4) + r][16 mt + (lane & 15)],
+// r = 0..3.  Every consumer stages whole tiles, so the order costs the others nothing.
+template <int M2>
+__device__ __forceinline__ void qfrag_rc(int f, int& row, int& col) {
+  constexpr int NTL = M2 / 16;
+  const int l = f & 63, t = (f >> 6) % NTL, mt = (f >> 6) / NTL;
+  row = 16 * t + 4 * (l >> 4); col = 16 * mt + (l & 15);
+}
+
+// inverse of block_pair: pair index and half (0: first block, 1: second) of block b at outer step `step`
+__device__ __forceinline__ void block_locate(int b, int step, int nblk, int& g, int& half) {
+  if (step < 0) { g = b >> 1; half = b & 1; return; }
+  int pos = 0;
+  if (b != 0) {
+    int v = b - 1 - step;                       // step <= nblk - 2: one wrap is enough
+    if (v < 0) v += nblk - 1;
+    pos = v + 1;
+  }
+  const int npair = nblk >> 1;
+  if (pos < npair) { g = pos; half = 0; } else { g = nblk - 1 - pos; half = 1; }
+}
+
+// V <- V Q runs on the fp16 MFMA pipe with split operands (hi = fp16(x), lo = fp16(x - hi): 22 significand bits; hi*hi +
+// hi*lo + lo*hi accumulated in fp32 -- the covariance kernel's scheme): the entries of V and Q are bounded by 1, and three
+// v_mfma_f32_16x16x32_f16 replace eight v_mfma_f32_16x16x4_f32 at a sixteenth of their cost each.  The rotation matrices
+// are therefore ALSO stored as fp16 fragments: unit u = ((mt * NCH + c) * 2 + part) * 64 + lane (16 bytes = 8 halfs;
+// part 0 = hi, 1 = lo; NCH = M2 / 32 K-chunks) holds the A operand of output tile mt and chunk c for lane (m, g) = (lane
+// & 15, lane >> 4): element j is Q[k][16 mt + m] with k = 16 (2 c + (j >> 2)) + 4 g + (j & 3).  That k-slot order is
+// what makes the accumulator layout of a 16 x 16 tile of V^T (lane (n, g), register r <-> V[n][4 g + r]) the B operand
+// of the next product without any data movement: elements 0..3 come from tile 2c, 4..7 from tile 2c + 1.
+template <int M2>
+__device__ __forceinline__ int qfrag16_k(int c, int g, int j) { return 16 * (2 * c + (j >> 2)) + 4 * g + (j & 3); }
+
+__device__ __forceinline__ void split_f16x8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (half_t)x[j];
+    lo[j] = (half_t)(x[j] - (float)hi[j]);
+  }
+}
+
+// =====================================================================================================================
+// Round 4: the cross step of a 64 x 64 pair problem with {S, Q} resident in REGISTERS (256 threads per pair problem).
+//
+// The round-2/3 kernel (jacobi_cross_sets_pw) keeps the {S, Q} image in LDS: 1024 threads, every one moves its 2 x 2 block
+// of both through LDS at every rotation set (4 x ds_read_b64 + 4 x ds_write_b64) and recomputes its addresses -- ~60
+// instructions per wave and set of which 24 are the rotation arithmetic; VALU issue and the LDS store path are both
+// about half busy (PMC round 3), nothing overlaps them but the second resident block.
+// Here (routing proven in tools/jacobi_patch_proto.py: routed sequence == plain sequence to 1e-16 for P = 1, 2, 4):
+//   * a lane owns a P x P PATCH of cells (P = 2: 4 cells = 32 floats), cell (k, l) = S[{p_k, q_k}] x [{p_l, q_l}] and
+//     Q[{k, 32 + k}] x [{p_l, q_l}] -- Q only takes column rotations, so its ROWS never move and its p columns never
+//     leave the lane; S[p_k][p_l] never leaves either;
+//   * cells are laid out in SKEWED coordinates (k, d), l = (k + d + 1) mod 32: the set s -> s+1 transition
+//     (q_x advances by one) is then a uniform nearest-neighbour shift -- pq, Qpq, Qqq from cell (k, d+1), qq from
+//     (k+1, d), qp from (k+1, d-1) -- most of it a register rename inside the patch; only the patch rim, 11 floats
+//     per lane and set (6 P - 1) instead of 32, goes through LDS, at addresses that are constants of the lane;
+//   * the cells (k, d = 0) produce S[p_k][q_k'] of the next set -- the pivots -- and live in the first 16 lanes of wave 0,
+//     which follow (pp, qq) of their two pairs in closed form exactly as the pivot wave of round 2 did and publish (c, s);
+//   * one barrier per set (4 waves instead of 16), ping-pong exchange buffers, no address arithmetic in the loop.
+// Per set a wave issues 4 cells x 24 rotation instructions + ~25 of exchange and control (was 4 waves x ~60 for the
+// same cells), and the LDS instructions drop from 40 (ds_*_b64) per four cells to 12.
+// =====================================================================================================================
+namespace r4 {
+constexpr int NT = 256;                    // threads per pair problem / per update task
+constexpr int SLOT_B = 48;                 // bytes a lane publishes per set: 11 floats + pad
+constexpr int SLOTS_B = NT * SLOT_B;       // one exchange buffer
+constexpr int CS_OFF = 2 * SLOTS_B;        // CS[2][32] float2 (c, s) behind the two exchange buffers
+constexpr int CS_B = 32 * 8;
+constexpr int DUMMY_OFF = CS_OFF + 2 * CS_B;   // 16 bytes that absorb the stores of lanes owning no pair
+constexpr int XCHG_B = DUMMY_OFF + 16;
+
+struct Patch {                             // P = 2: [i][j] = cell (k = 2 I + i, d = 2 Dd + j)
+  float pp[2][2], pq[2][2], qp[2][2], qq[2][2];
+  float Qpp[2][2], Qpq[2][2], Qqp[2][2], Qqq[2][2];
+};
+
+// The 32 cross sets on a patch-resident pair problem.  xb: exchange area (XCHG_B bytes of LDS), simg: the S image
+// [64][64] (read for the initial pivots only).  All 256 threads of the block call this together.
+template <bool PWAVE, bool DPP = true>
+__device__ __forceinline__ void cross_sets(Patch& R, unsigned char* xb, const float* simg, int t, float floor_m, float& my_off, float& my_sig) {
+  const int I = t & 15, Dd = t >> 4;
+  const bool piv = PWAVE && Dd == 0;                                   // lanes 0..15 of wave 0 own pairs 2 I, 2 I + 1
+  const int a_own = t * SLOT_B;
+  const int a_right = (((Dd + 1) & 15) * 16 + I) * SLOT_B;             // lane (I, Dd + 1)
+  const int a_down = (Dd * 16 + ((I + 1) & 15)) * SLOT_B;              // lane (I + 1, Dd)
+  const int a_left = (((Dd - 1) & 15) * 16 + I) * SLOT_B;              // lane (I, Dd - 1)
+  const int a_upleft = (((Dd - 1) & 15) * 16 + ((I + 1) & 15)) * SLOT_B;   // lane (I + 1, Dd - 1)
+  const int l0 = (2 * I + 2 * Dd + 1) & 31, l1 = (l0 + 1) & 31;        // l of cell (i, j) = l0 + i + j; l1 is even
+  const int a_k = CS_OFF + I * 16, a_l0 = CS_OFF + l0 * 8, a_l1 = CS_OFF + l1 * 8;
+  const int a_csw = piv ? CS_OFF + I * 16 : DUMMY_OFF;
+  float ppk[2] = {0.f, 0.f}, qqk[2] = {0.f, 0.f}, pqk[2] = {0.f, 0.f};  // the pivot blocks of pairs 2 I + i (pivot lanes)
+  if (PWAVE) {
+    __builtin_amdgcn_s_setprio(2);                                     // the chain of a set runs through this wave
+    f32x4 r = {1.f, 0.f, 1.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = (2 * I + i) & 31;
+      ppk[i] = simg[k * 64 + k]; qqk[i] = simg[(32 + k) * 64 + 32 + k]; pqk[i] = simg[k * 64 + 32 + k];   // set 0 pairs k with 32 + k
+      float c, s, off, sig;
+      jacobi_rotation(ppk[i], qqk[i], pqk[i], floor_m, c, s, off, sig);
+      if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
+      r[2 * i] = c; r[2 * i + 1] = s;
+    }
+    *reinterpret_cast<f32x4*>(xb + a_csw) = r;
+  }
+  __syncthreads();
+
+  auto assemble = [&](int buf_off) {                                   // the rim of the patch from the neighbours' slots
+    const unsigned char* sl = xb + buf_off;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(sl + a_right);
+    const f32x2 r1 = *reinterpret_cast<const f32x2*>(sl + a_right + 16);
+    const f32x2 d0 = *reinterpret_cast<const f32x2*>(sl + a_down + 24);
+    const float d1 = *reinterpret_cast<const float*>(sl + a_down + 32);
+    const float lf = *reinterpret_cast<const float*>(sl + a_left + 36);
+    const float ul = *reinterpret_cast<const float*>(sl + a_upleft + 40);
+    R.pq[0][0] = R.pq[0][1];   R.pq[0][1] = r0[0];
+    R.Qpq[0][0] = R.Qpq[0][1]; R.Qpq[0][1] = r0[1];
+    R.Qqq[0][0] = R.Qqq[0][1]; R.Qqq[0][1] = r0[2];
+    R.pq[1][0] = R.pq[1][1];   R.pq[1][1] = r0[3];
+    R.Qpq[1][0] = R.Qpq[1][1]; R.Qpq[1][1] = r1[0];
+    R.Qqq[1][0] = R.Qqq[1][1]; R.Qqq[1][1] = r1[1];
+    R.qq[0][0] = R.qq[1][0];   R.qq[0][1] = R.qq[1][1];  R.qq[1][0] = d0[0];  R.qq[1][1] = d0[1];
+    const float o10 = R.qp[1][0];
+    R.qp[0][0] = lf;  R.qp[0][1] = o10;  R.qp[1][1] = d1;  R.qp[1][0] = ul;
+  };
+
+  auto body = [&](auto CURC, auto INC) {
+    constexpr int CUR = decltype(CURC)::value, NX = CUR ^ 1;
+    constexpr bool IN = decltype(INC)::value;
+    const f32x4 rk = *reinterpret_cast<const f32x4*>(xb + CUR * CS_B + a_k);         // (c, s) of pairs 2 I, 2 I + 1
+    const f32x2 rl0 = *reinterpret_cast<const f32x2*>(xb + CUR * CS_B + a_l0);       // of pair l0
+    const f32x4 rl12 = *reinterpret_cast<const f32x4*>(xb + CUR * CS_B + a_l1);      // of pairs l0 + 1, l0 + 2
+    if (IN) assemble(CUR * SLOTS_B);
+    const float ck[2] = {rk[0], rk[2]}, sk[2] = {rk[1], rk[3]};
+    const float cl[3] = {rl0[0], rl12[0], rl12[2]}, sl[3] = {rl0[1], rl12[1], rl12[3]};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float c = cl[i + j], s = sl[i + j];
+        // columns (pair l) on S and Q, then rows (pair k) on S
+        const float ypp = c * R.pp[i][j] - s * R.pq[i][j], ypq = s * R.pp[i][j] + c * R.pq[i][j];
+        const float yqp = c * R.qp[i][j] - s * R.qq[i][j], yqq = s * R.qp[i][j] + c * R.qq[i][j];
+        R.pp[i][j] = ck[i] * ypp - sk[i] * yqp;  R.pq[i][j] = ck[i] * ypq - sk[i] * yqq;
+        R.qp[i][j] = sk[i] * ypp + ck[i] * yqp;  R.qq[i][j] = sk[i] * ypq + ck[i] * yqq;
+        const float a0 = R.Qpp[i][j], b0 = R.Qpq[i][j], a1 = R.Qqp[i][j], b1 = R.Qqq[i][j];
+        R.Qpp[i][j] = c * a0 - s * b0;  R.Qpq[i][j] = s * a0 + c * b0;
+        R.Qqp[i][j] = c * a1 - s * b1;  R.Qqq[i][j] = s * a1 + c * b1;
+      }
+    if (PWAVE) {
+      // pairs k = 2 I + i after this set (closed form from registers); the partner diagonal of the next set is the q
+      // diagonal pair k + 1 has just produced (own pair 1 for i = 0, pair 0 of lane I + 1 for i = 1); the next pivot
+      // element is this lane's own freshly rotated cell (i, 0)
+      float ppn[2], qqn[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float c2 = ck[i] * ck[i], s2 = sk[i] * sk[i], cs2 = 2.f * ck[i] * sk[i];
+        ppn[i] = c2 * ppk[i] - cs2 * pqk[i] + s2 * qqk[i];
+        qqn[i] = s2 * ppk[i] + cs2 * pqk[i] + c2 * qqk[i];
+      }
+      // lane I reads lane I + 1 of its 16-lane row (DPP row_ror:15: no LDS round trip on the chain)
+      const int q0 = __builtin_bit_cast(int, qqn[0]);
+      const float nb = DPP ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(q0, q0, 0x12F /* row_ror:15 */, 0xF, 0xF, false))
+                           : __shfl(qqn[0], (t & 48) | ((t + 1) & 15), 64);      // (A-B: the same through ds_bpermute)
+      ppk[0] = ppn[0]; qqk[0] = qqn[1]; pqk[0] = R.pq[0][0];
+      ppk[1] = ppn[1]; qqk[1] = nb;     pqk[1] = R.pq[1][0];
+      f32x4 r;
+      bool rot[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float c, s;
+        rot[i] = jacobi_rotation_cs(ppk[i], qqk[i], pqk[i], c, s);
+        r[2 * i] = c; r[2 * i + 1] = s;
+      }
+      *reinterpret_cast<f32x4*>(xb + NX * CS_B + a_csw) = r;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float off, sig;
+        jacobi_rotation_stats(ppk[i], qqk[i], pqk[i], floor_m, rot[i], off, sig);
+        if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
+      }
+    }
+    unsigned char* so = xb + NX * SLOTS_B + a_own;
+    *reinterpret_cast<f32x4*>(so) = f32x4{R.pq[0][0], R.Qpq[0][0], R.Qqq[0][0], R.pq[1][0]};
+    *reinterpret_cast<f32x4*>(so + 16) = f32x4{R.Qpq[1][0], R.Qqq[1][0], R.qq[0][0], R.qq[0][1]};
+    *reinterpret_cast<f32x4*>(so + 32) = f32x4{R.qp[0][0], R.qp[1][1], R.qp[0][1], 0.f};
+    __syncthreads();
+  };
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  body(C0{}, std::false_type{});                                       // set 0: the patch is as loaded
+#pragma unroll 1
+  for (int s = 1; s < 31; s += 2) {
+    body(C1{}, std::true_type{});
+    body(C0{}, std::true_type{});
+  }
+  body(C1{}, std::true_type{});                                        // set 31
+  assemble(0);                                                         // back in the arrangement of set 0
+  if (PWAVE) __builtin_amdgcn_s_setprio(0);
+}
+
+// D part: the pair problem (bi, bj) of matrix m at outer step p.step_d -- 256 threads (jacobi_fused_d: 1024)
+template <int M2, bool DPP = true>
+__device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, float* jsm) {
+  static_assert(M2 == 64, "the patch layout is written for 64 x 64 pair problems");
+  constexpr int B = M2 / 2, NW = M2 / 16, FR = M2 * M2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = p.C, nblk = C / B, npair = nblk / 2;
+  int bi, bj;
+  block_pair(g, p.step_d, nblk, bi, bj);
+  float floor_m = 0.f;
+  float my_off = 0.f, my_sig = 0.f, my_dm = 0.f;
+  bool finite = true;
+  float* Qo = p.Qw + ((size_t)m * npair + g) * FR;
+  float* So = p.Sw + ((size_t)m * npair + g) * FR;
+  half_t* Qo16 = p.Qw16 + ((size_t)m * npair + g) * (2 * FR);
+  float* Simg = jsm;                               // [M2][M2] floats (cross steps)
+  f32x2* SQ = reinterpret_cast<f32x2*>(jsm);       // [2][M2][M2 + 1] {S, Q} (intra step)
+  if (p.first) {
+    if (p.st[m].done) return;
+    floor_m = p.st[m].floor;
+    const float* Am = p.Pr + (size_t)m * C * C;
+    for (int e = tid; e < FR; e += NT) {
+      const int r = e / M2, c = e % M2;
+      const float v = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
+      finite &= fabsf(v) <= 3.0e38f;
+      if (r == c) my_dm = fmaxf(my_dm, fabsf(v));
+      if (p.step_d >= 0) Simg[e] = v;
+      else { f32x2 w; w[0] = v; w[1] = r == c ? 1.f : 0.f; SQ[r * (M2 + 1) + c] = w; }
+    }
+    __syncthreads();
+  } else {
+    // ---- look-ahead assembly (cross steps only): the diagonal blocks out of the images D(step_u) left behind, the
+    // off-diagonal block Q_g1[:, h1]^T . P_old[tile g1, g2] . Q_g2[:, h2] computed here (see jacobi_fused_d)
+    int g1, h1, g2, h2;
+    block_locate(bi, p.step_u, nblk, g1, h1);
+    block_locate(bj, p.step_u, nblk, g2, h2);
+    const float* S1 = p.Sr + ((size_t)m * npair + g1) * FR;
+    const float* S2 = p.Sr + ((size_t)m * npair + g2) * FR;
+    const bool same = g1 == g2;
+    float sv[FR / NT];
+#pragma unroll
+    for (int i = 0; i < FR / NT; ++i) {
+      const int e = tid + i * NT, r = e / M2, c = e % M2;
+      const bool rlo = r < B, clo = c < B;
+      const float* src = rlo ? S1 : S2;
+      const int rr = (rlo ? h1 : h2) * B + (rlo ? r : r - B);
+      const int cc = (clo ? h1 : h2) * B + (clo ? c : c - B);
+      sv[i] = (rlo == clo || same) ? src[rr * M2 + cc] : 0.f;
+    }
+    float* Xs = jsm;                                // [M2][M2 + 1]  tile (g1, g2) of the state before U(step_u)
+    float* Q1s = Xs + M2 * (M2 + 1);                // [M2][B + 1]   columns h1 of Q_g1
+    float* Q2s = Q1s + M2 * (B + 1);                // [M2][B + 1]   columns h2 of Q_g2
+    float* Ws = Q2s + M2 * (B + 1);                 // [B][M2 + 1]   Q_g1[:, h1]^T X
+    constexpr int NV = FR / 4 / NT;                 // float4 per thread of a 64 x 64 tile
+    f32x4 xv[NV], qv[NV];
+    float* Qdst[NV];
+    int xr[NV], xc[NV];
+    if (!same) {
+      int b1i, b1j, b2i, b2j;
+      block_pair(g1, p.step_u, nblk, b1i, b1j);
+      block_pair(g2, p.step_u, nblk, b2i, b2j);
+      const float* Pm = p.Pr + (size_t)m * C * C;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int idx = tid + i * NT, se = idx * 4;
+        xr[i] = se / M2; xc[i] = se % M2;
+        xv[i] = *reinterpret_cast<const f32x4*>(Pm + (size_t)pair_index<B>(xr[i], b1i, b1j) * C + pair_index<B>(xc[i], b2i, b2j));
+        // Q columns: M2 x B floats per side = FR / 8 float4 (the fragments of that half); first half of the indices
+        // fetches Q_g1, second half Q_g2
+        const bool one = idx < FR / 8;
+        const int t2 = one ? idx : idx - FR / 8;
+        const int f = (one ? h1 : h2) * (FR / 8) + t2;
+        int qr, qc;
+        qfrag_rc<M2>(f, qr, qc);
+        qc -= (one ? h1 : h2) * B;
+        qv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + (one ? g1 : g2)) * FR + (size_t)f * 4);
+        Qdst[i] = (one ? Q1s : Q2s) + qr * (B + 1) + qc;
+      }
+    }
+    if (p.st[m].done) return;                       // (block-uniform)
+    floor_m = p.st[m].floor;
+    f32x4 crit = {0.f, 0.f, 0.f, 0.f};
+    const int li = lane & 15, lq = lane >> 4;
+    if (!same) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Xs[xr[i] * (M2 + 1) + xc[i] + j] = xv[i][j]; Qdst[i][j * (B + 1)] = qv[i][j]; }
+      __syncthreads();
+#pragma unroll
+      for (int jb = 0; jb < (B / 16) * NW / (NT / 64); ++jb) {          // W = Q_g1[:, h1]^T X   (B x M2): two tiles per wave
+        const int job = wave * ((B / 16) * NW / (NT / 64)) + jb, tr = job / NW, tj = job % NW;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int kk = 0; kk < M2; kk += 4)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Q1s[(kk + lq) * (B + 1) + 16 * tr + li], Xs[(kk + lq) * (M2 + 1) + 16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ws[(16 * tr + 4 * lq + r) * (M2 + 1) + 16 * tj + li] = acc[r];
+      }
+      __syncthreads();
+      {                                                                 // crit = W Q_g2[:, h2]   (B x B): one tile per wave
+        const int tr = wave / (B / 16), tc = wave % (B / 16);
+#pragma unroll 4
+        for (int kk = 0; kk < M2; kk += 4)
+          crit = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * tr + li) * (M2 + 1) + kk + lq], Q2s[(kk + lq) * (B + 1) + 16 * tc + li], crit, 0, 0, 0);
+      }
+      __syncthreads();                              // the staging area becomes the image
+    }
+#pragma unroll
+    for (int i = 0; i < FR / NT; ++i) {
+      const int e = tid + i * NT, r = e / M2, c = e % M2;
+      if ((r < B) == (c < B) || same) {
+        Simg[e] = sv[i];
+        finite &= fabsf(sv[i]) <= 3.0e38f;
+        if (r == c) my_dm = fmaxf(my_dm, fabsf(sv[i]));
+      }
+    }
+    if (!same) {
+      const int tr = wave / (B / 16), tc = wave % (B / 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tr + 4 * lq + r, col = B + 16 * tc + li;
+        Simg[row * M2 + col] = crit[r];
+        Simg[col * M2 + row] = crit[r];
+        finite &= fabsf(crit[r]) <= 3.0e38f;
+      }
+    }
+    __syncthreads();
+  }
+  float* Qimg = jsm + FR;                           // [M2][M2] floats (cross steps: epilogue only)
+  if (p.step_d >= 0) {
+    // ---- the patch out of the image, 32 sets, the patch back into the S and Q images
+    const int I = tid & 15, Dd = tid >> 4;
+    Patch R;
+    int ka[2], la[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ka[i] = 2 * I + i;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = ka[i], l = (k + 2 * Dd + j + 1) & 31;
+        la[i][j] = l;
+        R.pp[i][j] = Simg[k * M2 + l];        R.pq[i][j] = Simg[k * M2 + B + l];
+        R.qp[i][j] = Simg[(B + k) * M2 + l];  R.qq[i][j] = Simg[(B + k) * M2 + B + l];
+        R.Qpp[i][j] = k == l ? 1.f : 0.f;  R.Qqq[i][j] = R.Qpp[i][j];
+        R.Qpq[i][j] = 0.f;  R.Qqp[i][j] = 0.f;
+      }
+    }
+    unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + FR);
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) cross_sets<true, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
+    else cross_sets<false, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
+    __syncthreads();                                // every lane has taken its last rim: the exchange area becomes the Q image
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int k = ka[i], l = la[i][j];
+        Simg[k * M2 + l] = R.pp[i][j];        Simg[k * M2 + B + l] = R.pq[i][j];
+        Simg[(B + k) * M2 + l] = R.qp[i][j];  Simg[(B + k) * M2 + B + l] = R.qq[i][j];
+        Qimg[k * M2 + l] = R.Qpp[i][j];       Qimg[k * M2 + B + l] = R.Qpq[i][j];
+        Qimg[(B + k) * M2 + l] = R.Qqp[i][j]; Qimg[(B + k) * M2 + B + l] = R.Qqq[i][j];
+      }
+    __syncthreads();
+    constexpr int NCH = M2 / 32;
+#pragma unroll
+    for (int i = 0; i < FR / 4 / NT; ++i) {
+      const int f = tid + i * NT;
+      *reinterpret_cast<f32x4*>(So + (size_t)f * 4) = *reinterpret_cast<const f32x4*>(Simg + f * 4);
+      int qr, qc;
+      qfrag_rc<M2>(f, qr, qc);                      // fragment order (see qfrag_rc)
+      f32x4 q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = Qimg[(qr + j) * M2 + qc];
+      *reinterpret_cast<f32x4*>(Qo + (size_t)f * 4) = q;
+      // fp16 hi / lo fragment unit f
+      const int l16 = f & 63, part = (f >> 6) & 1, cc = (f >> 7) % NCH, mt = (f >> 7) / NCH;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = Qimg[qfrag16_k<M2>(cc, l16 >> 4, j) * M2 + 16 * mt + (l16 & 15)];
+      half8 hi, lo;
+      split_f16x8(x, hi, lo);
+      *reinterpret_cast<half8*>(Qo16 + (size_t)f * 8) = part ? lo : hi;
+    }
+  } else {
+    constexpr int PITCH = M2 + 1, KB = (M2 / 2) * (M2 / 2) / NT;
+    float* DO = jsm + 4 * M2 * PITCH;
+    const int cur = jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, floor_m, my_off, my_sig);
+    const f32x2* img = SQ + cur * M2 * PITCH;
+    constexpr int NCH = M2 / 32;
+    for (int e = tid; e < FR; e += NT) So[e] = img[(e / M2) * PITCH + (e % M2)][0];
+#pragma unroll
+    for (int i = 0; i < FR / 4 / NT; ++i) {
+      const int f = tid + i * NT;
+      int qr, qc;
+      qfrag_rc<M2>(f, qr, qc);
+      f32x4 q;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = img[(qr + j) * PITCH + qc][1];
+      *reinterpret_cast<f32x4*>(Qo + (size_t)f * 4) = q;
+      const int l16 = f & 63, part = (f >> 6) & 1, cc = (f >> 7) % NCH, mt = (f >> 7) / NCH;
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = img[qfrag16_k<M2>(cc, l16 >> 4, j) * PITCH + 16 * mt + (l16 & 15)][1];
+      half8 hi, lo;
+      split_f16x8(x, hi, lo);
+      *reinterpret_cast<half8*>(Qo16 + (size_t)f * 8) = part ? lo : hi;
+    }
+  }
+  if (!finite) my_off = __builtin_inff();
+  for (int o = 32; o > 0; o >>= 1) {
+    my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
+    my_sig = fmaxf(my_sig, __shfl_xor(my_sig, o, 64));
+    my_dm = fmaxf(my_dm, __shfl_xor(my_dm, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    if (my_off > 0.f) atomicMax(&p.st[m].offmax, __float_as_uint(my_off));
+    if (my_sig > 0.f) atomicMax(&p.st[m].offsig, __float_as_uint(my_sig));
+    if (my_dm > 0.f && my_dm < 3.0e38f) atomicMax(&p.st[m].dmax, __float_as_uint(my_dm));
+  }
+}
+
+// U part: one task of the tile update (see jacobi_fused_u) by 256 threads: a wave owns a 16-row strip of the 64 x 64 tile
+// (four 16 x 16 MFMA tiles); per output tile the operands, k-slots and MFMA order are those of the 1024-thread version.
+template <int M2>
+__device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int task, float* jsm) {
+  constexpr int B = M2 / 2, PITCH = M2 + 1, NW = M2 / 16, FR = M2 * M2, NV = FR / 4 / NT;
+  static_assert(NT / 64 == NW, "one 16-row strip per wave");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = p.C, nblk = C / B, npair = nblk / 2;
+  const int n_off = npair * (npair - 1) / 2;
+  const size_t cc = (size_t)C * C;
+  if (task >= n_off && task < n_off + npair) {            // diagonal tile g: the image D(step_u) left behind
+    const int g = task - n_off;
+    int gi, gj;
+    block_pair(g, p.step_u, nblk, gi, gj);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e4 = (tid + i * NT) * 4, lr = e4 / M2, lc = e4 % M2;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p.Sr + ((size_t)m * npair + g) * FR + e4);
+      *reinterpret_cast<f32x4*>(p.Pw + m * cc + (size_t)pair_index<B>(lr, gi, gj) * C + pair_index<B>(lc, gi, gj)) = v;
+    }
+    return;
+  }
+  const bool is_v = task >= n_off;               // (V tasks exist only in launches with_v)
+  int g, h;
+  if (is_v) { const int t = task - n_off - npair; g = t / npair; h = t % npair; }       // g = M2-row block of V
+  else { int t = task; g = 0; while (t >= npair - 1 - g) { t -= npair - 1 - g; ++g; } h = g + 1 + t; }
+  int hi, hj, gi = 0, gj = 0;
+  block_pair(h, p.step_u, nblk, hi, hj);
+  if (!is_v) block_pair(g, p.step_u, nblk, gi, gj);
+  float* Xs = jsm;
+  float* Qhs = Xs + M2 * PITCH;
+  float* Qgs = Qhs + M2 * PITCH;
+  {
+    const float* X = is_v ? p.V + m * cc : p.Pr + m * cc;
+    f32x4 xv[NV], hv[NV], gv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT, e4 = f * 4, lr = e4 / M2, lc = e4 % M2;
+      const int gr = is_v ? g * M2 + lr : pair_index<B>(lr, gi, gj);
+      xv[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * C + pair_index<B>(lc, hi, hj));
+      hv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + h) * FR + e4);
+      gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!is_v) gv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + g) * FR + e4);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT, e4 = f * 4, lr = e4 / M2, lc = e4 % M2;
+      int qr, qc;
+      qfrag_rc<M2>(f, qr, qc);                      // the rotations arrive in fragment order
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        Xs[lr * PITCH + lc + j] = xv[i][j];
+        Qhs[(qr + j) * PITCH + qc] = hv[i][j];
+        if (!is_v) Qgs[(qr + j) * PITCH + qc] = gv[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  const int ti = wave, li = lane & 15, lq = lane >> 4;
+  f32x4 acc[NW];
+#pragma unroll
+  for (int tj = 0; tj < NW; ++tj) acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (is_v) {
+    constexpr int NCH = M2 / 32;
+    const half_t* q16 = p.Qr16 + ((size_t)m * npair + h) * (2 * FR);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = Xs[(16 * ti + li) * PITCH + qfrag16_k<M2>(c, lq, j)];
+      half8 bh, bl;
+      split_f16x8(x, bh, bl);
+#pragma unroll
+      for (int tj = 0; tj < NW; ++tj) {
+        const half8 ah = *reinterpret_cast<const half8*>(q16 + ((size_t)((tj * NCH + c) * 2 + 0) * 64 + lane) * 8);
+        const half8 al = *reinterpret_cast<const half8*>(q16 + ((size_t)((tj * NCH + c) * 2 + 1) * 64 + lane) * 8);
+        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[tj], 0, 0, 0);
+        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[tj], 0, 0, 0);
+        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[tj], 0, 0, 0);
+      }
+    }
+    float* Vm = p.V + m * cc;
+#pragma unroll
+    for (int tj = 0; tj < NW; ++tj)
+      *reinterpret_cast<f32x4*>(Vm + (size_t)(g * M2 + 16 * ti + li) * C + pair_index<B>(16 * tj + 4 * lq, hi, hj)) = acc[tj];
+    return;
+  }
+#pragma unroll 2
+  for (int kk = 0; kk < M2; kk += 4) {      // T = X Qh
+    const float a = Xs[(16 * ti + li) * PITCH + kk + lq];
+#pragma unroll
+    for (int tj = 0; tj < NW; ++tj)
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Qhs[(kk + lq) * PITCH + 16 * tj + li], acc[tj], 0, 0, 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tj = 0; tj < NW; ++tj) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[(16 * ti + 4 * lq + r) * PITCH + 16 * tj + li] = acc[tj][r];
+    acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+#pragma unroll 2
+  for (int kk = 0; kk < M2; kk += 4) {      // Y = Qg^T T
+    const float a = Qgs[(kk + lq) * PITCH + 16 * ti + li];
+#pragma unroll
+    for (int tj = 0; tj < NW; ++tj)
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[(kk + lq) * PITCH + 16 * tj + li], acc[tj], 0, 0, 0);
+  }
+  float* Pw = p.Pw + m * cc;
+#pragma unroll
+  for (int tj = 0; tj < NW; ++tj) {
+    const int col = pair_index<B>(16 * tj + li, hi, hj);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Pw[(size_t)pair_index<B>(16 * ti + 4 * lq + r, gi, gj) * C + col] = acc[tj][r];
+    // mirror tile (h, g): this lane's four rows are four consecutive columns there
+    *reinterpret_cast<f32x4*>(Pw + (size_t)col * C + pair_index<B>(16 * ti + 4 * lq, gi, gj)) = acc[tj];
+  }
+}
+}  // namespace r4

@@ -508,201 +508,8 @@ __global__ void cov_finish_kernel(const float* partial, const float* scale, floa
 //   fp32 MFMA (jacobi_update_kernel).  Two launches per step, C/B-1 steps per sweep.
 //   A per-matrix `done` flag turns later launches into no-ops.
 // ---------------------------------------------------------------------------
-struct JacobiState {
-  unsigned int offmax;   // max |a_pq|/sqrt(a_pp a_qq) over the pairs rotated this sweep (float bits)
-  int done;              // 0 rotating, 1 converged, 2 failed: non-finite input
-  int sweeps;
-  unsigned int offsig;   // the same maximum over the SIGNIFICANT pairs only (a diagonal above `floor`)
-  float floor;           // 1e-4 max|a_ii| of the previous sweep (-> 1e-4 lambda_max): diagonals below it are taken to belong
-                         // to the numerical null space of a matrix of this norm (~1700 eps ||A||) when the STATUS is judged
-  unsigned int last_sig; // offsig of the last completed sweep (what jacobi_finalize_kernel judges)
-  unsigned int dmax;     // max |a_ii| seen by this sweep's pair problems (float bits)
-  float r2;              // strict residual measure of the last completed sweep (jacobi_resid_kernel), -1 before the first
-  float r2l;             // the lenient one (what the final status is judged by)
-  int pad;               // look-ahead path: the buffer (0: A, 1: the second one) that held the matrix when it was declared done
-  int seg_stop;          // number of launch segments whose rotations belong to this matrix (INT_MAX while it is still rotating)
-  int pad2;
-};
-constexpr int JACOBI_RESID_CHUNKS = 16;
-constexpr float JACOBI_SIG_FLOOR = 1e-4f;
+#include "jacobi_dev.h"
 
-__device__ __forceinline__ int rr_idx(int pos, int step, int n) {
-  // circle method: position 0 is fixed, the other n-1 rotate
-  if (pos == 0) return 0;
-  int v = pos - 1 + step;
-  if (v >= n - 1) v -= n - 1;
-  return v + 1;
-}
-
-// blocks (bi, bj) of pair g at outer step `step`; step < 0 is the intra step: neighbours (2g, 2g+1)
-__device__ __forceinline__ void block_pair(int g, int step, int nblk, int& bi, int& bj) {
-  if (step < 0) { bi = 2 * g; bj = 2 * g + 1; }
-  else { bi = rr_idx(g, step, nblk); bj = rr_idx(nblk - 1 - g, step, nblk); }
-}
-
-template <int B>
-__device__ __forceinline__ int pair_index(int r, int bi, int bj) {
-  return r < B ? bi * B + r : bj * B + (r - B);
-}
-
-constexpr float JACOBI_ROT_TOL = 1e-6f;    // skip rotations below this relative size
-constexpr float JACOBI_CONV_TOL = 1e-2f;   // a sweep that never saw more than this is the last one (quadratic convergence;
-                                           // measured: WCT error vs the oracle identical for 2e-3 and 1e-2, 100x worse at 5e-2)
-constexpr float JACOBI_FLOOR = 1e-6f;      // both diagonals below this: the pair cannot reach the 1e-5 cut-off
-
-// rotation (c, s) that annihilates a_pq; `off` = pre-rotation relative size (0 if skipped).
-// t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (a_qq - a_pp) / (2 a_pq), written as
-// t = +-|a_pq| / (|tau| + sqrt(tau^2 + a_pq^2)), tau = (a_qq - a_pp)/2: three transcendentals
-// on the dependent chain (sqrt, rcp, rsq) and no division by a_pq.
-// `sig` = the same measure if the pair is significant (its larger diagonal is above the matrix' noise floor), else 0:
-// pairs inside the numerical null space keep relative off-diagonals of O(1) for ever (every update regenerates
-// rounding noise there) without mattering for f(A); they are still rotated, but they do not count as "not converged".
-// The same in two parts for the pivot wave of jacobi_cross_sets_pw: the rotation itself is on the serial chain of a set
-// (it gates every other wave at the barrier), the convergence statistics are not -- they are evaluated after (c, s) has
-// been published, under the latency of that LDS write.
-__device__ __forceinline__ bool jacobi_rotation_cs(float app, float aqq, float apq, float& c, float& s) {
-  const float den2 = fabsf(app * aqq);
-  const float aapq = fabsf(apq);
-  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
-  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
-  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
-  const float tau = 0.5f * (aqq - app);
-  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
-  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
-  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
-  const float n2 = 1.f + t * t;
-  float r = __builtin_amdgcn_rsqf(n2);
-  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
-  c = rot ? r : 1.f;
-  s = rot ? r * t : 0.f;
-  return rot;
-}
-__device__ __forceinline__ void jacobi_rotation_stats(float app, float aqq, float apq, float floor_m, bool rot, float& off, float& sig) {
-  const float den2 = fabsf(app * aqq);
-  const float aapq = fabsf(apq);
-  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
-  const float rel = den2 > 0.f ? fminf(aapq * __builtin_amdgcn_rsqf(den2), 1.f) : 1.f;
-  off = rot ? rel : 0.f;
-  // branch-free (selects, not exec-mask branches: the pivot wave is the pole of every set)
-  const float mixed = fmaxf(aapq * __builtin_amdgcn_rcpf(big), small < 1e-5f ? 0.1f * aapq * __builtin_amdgcn_rsqf(big * 1e-5f) : 0.f);
-  const float sig_mixed = big > floor_m ? fminf(off, mixed) : 0.f;
-  sig = small > floor_m ? off : sig_mixed;
-}
-
-__device__ __forceinline__ void jacobi_rotation(float app, float aqq, float apq, float floor_m, float& c, float& s, float& off, float& sig) {
-  const float den2 = fabsf(app * aqq);
-  const float aapq = fabsf(apq);
-  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
-  // (a) both diagonals far below the 1e-5 cut-off: whatever they mix stays dropped;
-  // (b) coupling of a kept direction into a noise-level one with a negligible angle
-  // bitwise & / | on the predicates: && would become an exec-mask branch around the second half
-  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
-  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
-  const float rel = den2 > 0.f ? fminf(aapq * __builtin_amdgcn_rsqf(den2), 1.f) : 1.f;
-  const float tau = 0.5f * (aqq - app);
-  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
-  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
-  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
-  const float n2 = 1.f + t * t;
-  float r = __builtin_amdgcn_rsqf(n2);
-  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
-  c = rot ? r : 1.f;
-  s = rot ? r * t : 0.f;
-  off = rot ? rel : 0.f;
-  // both diagonals significant: the cosine; one significant, the other inside the rounding noise (a cosine against
-  // it cannot settle): the rotation angle a_pq / big, and -- if the small one is below the reference's 1e-5 cut-off --
-  // that it stays there: contamination a_pq^2 / big below 1 % of the cut-off; none significant: does not count
-  const float mixed = fmaxf(aapq * __builtin_amdgcn_rcpf(big), small < 1e-5f ? 0.1f * aapq * __builtin_amdgcn_rsqf(big * 1e-5f) : 0.f);
-  sig = small > floor_m ? off : (big > floor_m ? fminf(off, mixed) : 0.f);
-}
-
-// Rotation sets on an N x N symmetric pair problem (N = 32 or 64: blocks I = 0..N/2-1 and
-// J = N/2..N-1) held in LDS, by (N/2)^2 threads t = (k, l), N/2 disjoint pairs per set.
-// S and the accumulated rotations Q are interleaved as float2 {S[r][c], Q[r][c]} so thread
-// (k, l) moves its 2x2 block of both with four 8-byte LDS reads and writes (rows {p_k, q_k} x
-// columns {p_l, q_l}).  Two LDS images ping-pong, so a rotation set costs ONE barrier.  Each
-// thread derives rotation(l) from three more reads; rotation(k) is fetched from the lane of
-// its own wave that has l == k (ds_bpermute: no LDS round trip, no serial section).
-//   SWEEP_CROSS  the (N/2)^2 pairs (i in I, j in J), N/2 sets     -- one outer step
-//   SWEEP_INTRA  the pairs inside I and inside J, N/2-1 sets      -- once per outer sweep
-// so that one outer sweep visits every pair of the C indices exactly once (a true cyclic
-// Jacobi sweep).  All threads of the block call this together (contains __syncthreads()).
-// Returns the index of the image that holds the result.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-enum { SWEEP_CROSS = 1, SWEEP_INTRA = 2 };
-template <int MODE, int N>
-__device__ __forceinline__ void sweep_pair(int j, int s, int& p, int& q) {
-  constexpr int NP = N / 2;
-  if (MODE == SWEEP_CROSS) { p = j; q = NP + ((j + s) & (NP - 1)); }
-  else { const int base = j & (NP / 2) ? NP : 0, jj = j & (NP / 2 - 1); p = base + rr_idx(jj, s, NP); q = base + rr_idx(NP - 1 - jj, s, NP); }
-}
-//
-// In CROSS mode the three values every thread needs for rotation(l) -- S[p][p], S[q][q], S[p][q] --
-// are mirrored in two small compact arrays (DO: diagonal D[2][N] and pair elements O[2][N/2]), kept
-// current by the threads that own them; reading them straight out of the float2 image costs three
-// 4-way bank-conflicted loads per thread and set (the diagonal has stride 2(N+2) dwords).
-// KB = 2x2 blocks per thread (rows k, k + NP/KB, ...; one column pair l): rotation(l) is derived once
-// per thread and reused for its KB blocks.
-template <int MODE, int N, int KB>
-__device__ __forceinline__ int jacobi_sets(f32x2* SQ, float* DO, int t, float floor_m, float& my_off, float& my_sig) {
-  constexpr int NP = N / 2, PITCH = N + 1, IMG = N * PITCH, KS = NP / KB;
-  constexpr int NSETS = MODE == SWEEP_CROSS ? NP : NP - 1;
-  const int kq = t / NP, l = t % NP;
-  float* const Dg = DO;                          // [2][N]
-  float* const Og = DO + 2 * N;                  // [2][NP]
-  if (MODE == SWEEP_CROSS) {
-    for (int i = t; i < N; i += NP * KS) Dg[i] = SQ[i * PITCH + i][0];
-    for (int i = t; i < NP; i += NP * KS) Og[i] = SQ[i * PITCH + NP + i][0];      // set 0 pairs j with NP + j
-    __syncthreads();
-  }
-  int cur = 0;
-  for (int s = 0; s < NSETS; ++s) {
-    int pl, ql;
-    sweep_pair<MODE, N>(l, s, pl, ql);
-    const f32x2* C0 = SQ + cur * IMG;
-    f32x2* N0 = SQ + (cur ^ 1) * IMG;
-    // every LDS read of the set is issued before anything depends on it
-    float lpp, lqq, lpq;
-    if (MODE == SWEEP_CROSS) { lpp = Dg[cur * N + pl]; lqq = Dg[cur * N + ql]; lpq = Og[cur * NP + l]; }
-    else { lpp = C0[pl * PITCH + pl][0]; lqq = C0[ql * PITCH + ql][0]; lpq = C0[pl * PITCH + ql][0]; }
-    int pk[KB], qk[KB];
-    f32x2 app[KB], apq[KB], aqp[KB], aqq[KB];
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      sweep_pair<MODE, N>(kq + i * KS, s, pk[i], qk[i]);
-      app[i] = C0[pk[i] * PITCH + pl]; apq[i] = C0[pk[i] * PITCH + ql];
-      aqp[i] = C0[qk[i] * PITCH + pl]; aqq[i] = C0[qk[i] * PITCH + ql];
-    }
-    float cl, sl, offl, sigl;
-    jacobi_rotation(lpp, lqq, lpq, floor_m, cl, sl, offl, sigl);
-    my_off = fmaxf(my_off, offl);
-    my_sig = fmaxf(my_sig, sigl);
-    const int nx = cur ^ 1;
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      const int k = kq + i * KS;
-      const int src_lane = (t & (64 - NP)) | k;      // lane of my wave whose l equals this k
-      const float ck = __shfl(cl, src_lane, 64), sk = __shfl(sl, src_lane, 64);
-      // S: columns (pair l), then rows (pair k);  Q: columns only
-      const float ypp = cl * app[i][0] - sl * apq[i][0], ypq = sl * app[i][0] + cl * apq[i][0];
-      const float yqp = cl * aqp[i][0] - sl * aqq[i][0], yqq = sl * aqp[i][0] + cl * aqq[i][0];
-      f32x2 npp, npq, nqp, nqq;
-      npp[0] = ck * ypp - sk * yqp;  npq[0] = ck * ypq - sk * yqq;
-      nqp[0] = sk * ypp + ck * yqp;  nqq[0] = sk * ypq + ck * yqq;
-      npp[1] = cl * app[i][1] - sl * apq[i][1];  npq[1] = sl * app[i][1] + cl * apq[i][1];
-      nqp[1] = cl * aqp[i][1] - sl * aqq[i][1];  nqq[1] = sl * aqp[i][1] + cl * aqq[i][1];
-      N0[pk[i] * PITCH + pl] = npp;  N0[pk[i] * PITCH + ql] = npq;
-      N0[qk[i] * PITCH + pl] = nqp;  N0[qk[i] * PITCH + ql] = nqq;
-      if (MODE == SWEEP_CROSS) {
-        if (k == l) { Dg[nx * N + pk[i]] = npp[0]; Dg[nx * N + qk[i]] = nqq[0]; }
-        if (l == ((k + 1) & (NP - 1))) Og[nx * NP + k] = npq[0];     // S[p_k][q_k] of the next set
-      }
-    }
-    cur ^= 1;
-    __syncthreads();
-  }
-  return cur;
-}
 
 
 // The cross sweep (one outer step: N/2 rotation sets over the (N/2)^2 pairs (i in I, j in J)), written for
@@ -1091,63 +898,6 @@ __device__ unsigned long long jac_ts[8192 * 10];
 #else
 #define JTS(slot) do {} while (0)
 #endif
-struct JacobiFusedArgs {
-  const float* Pr;      // [nmat][C][C] state the U part reads and the D part takes its look-ahead block from
-  float* Pw;            // [nmat][C][C] state the U part writes
-  float* V;             // [nmat][C][C] eigenvector accumulation, in place
-  const float* Qr; const float* Sr;   // [nmat][npair][M2*M2] rotations / rotated pair problems of step_u
-  float* Qw; float* Sw;               // ... written by the D part (step_d)
-  const half_t* Qr16; half_t* Qw16;   // the same rotations split into fp16 hi + lo MFMA fragments (V <- V Q; see qfrag16)
-  JacobiState* st;
-  int C, nmat;
-  int step_d, step_u;   // outer step of the pair problems / of the tile update (= the step before step_d)
-  int has_d, has_u;
-  int first;            // the D part loads its pair problems straight from Pr (nothing is pending on it)
-  int with_v;           // the U part also updates V (otherwise jacobi_vstrip_kernel applies the segment's rotations later)
-  int dbg;              // timing experiments (WCT_JACOBI_DBG): 1 U blocks exit at once, 2 D blocks exit at once, 4 no rotation sets
-};
-
-// Rotation matrices are stored in FRAGMENT order (the A operand of v_mfma_f32_16x16x4_f32 for V Q, see
-// jacobi_vstrip_kernel): float4 f = (mt * (M2/16) + t) * 64 + lane holds Q[16 t + 4 (lane >> 4) + r][16 mt + (lane & 15)],
-// r = 0..3.  Every consumer stages whole tiles, so the order costs the others nothing.
-template <int M2>
-__device__ __forceinline__ void qfrag_rc(int f, int& row, int& col) {
-  constexpr int NTL = M2 / 16;
-  const int l = f & 63, t = (f >> 6) % NTL, mt = (f >> 6) / NTL;
-  row = 16 * t + 4 * (l >> 4); col = 16 * mt + (l & 15);
-}
-
-// inverse of block_pair: pair index and half (0: first block, 1: second) of block b at outer step `step`
-__device__ __forceinline__ void block_locate(int b, int step, int nblk, int& g, int& half) {
-  if (step < 0) { g = b >> 1; half = b & 1; return; }
-  int pos = 0;
-  if (b != 0) {
-    int v = b - 1 - step;                       // step <= nblk - 2: one wrap is enough
-    if (v < 0) v += nblk - 1;
-    pos = v + 1;
-  }
-  const int npair = nblk >> 1;
-  if (pos < npair) { g = pos; half = 0; } else { g = nblk - 1 - pos; half = 1; }
-}
-
-// V <- V Q runs on the fp16 MFMA pipe with split operands (hi = fp16(x), lo = fp16(x - hi): 22 significand bits; hi*hi +
-// hi*lo + lo*hi accumulated in fp32 -- the covariance kernel's scheme): the entries of V and Q are bounded by 1, and three
-// v_mfma_f32_16x16x32_f16 replace eight v_mfma_f32_16x16x4_f32 at a sixteenth of their cost each.  The rotation matrices
-// are therefore ALSO stored as fp16 fragments: unit u = ((mt * NCH + c) * 2 + part) * 64 + lane (16 bytes = 8 halfs;
-// part 0 = hi, 1 = lo; NCH = M2 / 32 K-chunks) holds the A operand of output tile mt and chunk c for lane (m, g) = (lane
-// & 15, lane >> 4): element j is Q[k][16 mt + m] with k = 16 (2 c + (j >> 2)) + 4 g + (j & 3).  That k-slot order is
-// what makes the accumulator layout of a 16 x 16 tile of V^T (lane (n, g), register r <-> V[n][4 g + r]) the B operand
-// of the next product without any data movement: elements 0..3 come from tile 2c, 4..7 from tile 2c + 1.
-template <int M2>
-__device__ __forceinline__ int qfrag16_k(int c, int g, int j) { return 16 * (2 * c + (j >> 2)) + 4 * g + (j & 3); }
-
-__device__ __forceinline__ void split_f16x8(const float (&x)[8], half8& hi, half8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    hi[j] = (half_t)x[j];
-    lo[j] = (half_t)(x[j] - (float)hi[j]);
-  }
-}
 
 template <int M2>
 static size_t jacobi_fused_lds(int has_d, int has_u, int first, int step_d) {
@@ -1460,6 +1210,44 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_
     const int task = b / p.nmat, m = b % p.nmat;
     if (p.st[m].done || (p.dbg & 1)) return;
     jacobi_fused_u<M2>(p, m, task, jsm);
+  }
+}
+
+namespace r4 {
+template <int M2>
+static size_t fused_lds(int has_d, int has_u, int first, int step_d) {
+  constexpr int B = M2 / 2;
+  size_t need = 0;
+  if (has_d) {
+    if (step_d < 0) need = jacobi_diag_lds<M2>(-1, true);                               // intra sets: two {S, Q} images
+    else {
+      need = (size_t)M2 * M2 * sizeof(float) + XCHG_B;                                  // S image, exchange area
+      need = std::max(need, (size_t)2 * M2 * M2 * sizeof(float));                       // S and Q images of the epilogue
+      if (!first) need = std::max(need, (size_t)(M2 * (M2 + 1) + 2 * M2 * (B + 1) + B * (M2 + 1)) * sizeof(float));
+    }
+  }
+  if (has_u) need = std::max(need, (size_t)3 * M2 * (M2 + 1) * sizeof(float));
+  return need;
+}
+}  // namespace r4
+
+
+// grid: [nmat * npair pair problems (if has_d)] [ntask * nmat update tasks, task-major (if has_u)]; 256 threads
+template <int M2, bool DPP>
+__global__ __launch_bounds__(r4::NT, 3) void jacobi_fused4_kernel(JacobiFusedArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float jsm[];
+  constexpr int B = M2 / 2;
+  const int npair = p.C / B / 2;
+  const int n_d = p.has_d ? p.nmat * npair : 0;
+  int b = blockIdx.x;
+  if (b < n_d) {
+    const int m = b / npair, g = b % npair;
+    r4::fused_d<M2, DPP>(p, m, g, jsm);
+  } else {
+    b -= n_d;
+    const int task = b / p.nmat, m = b % p.nmat;
+    if (p.st[m].done) return;
+    r4::fused_u<M2>(p, m, task, jsm);
   }
 }
 
@@ -1945,6 +1733,11 @@ static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
   return WCT_OK;
 }
 
+static int jacobi_r4_mode() {
+  static const int on = getenv("WCT_JACOBI_R4") ? atoi(getenv("WCT_JACOBI_R4")) : 1;
+  return on;
+}
+
 // ---- look-ahead orchestration -------------------------------------------------------------------------------------
 // launch { D(step_d) writing log slot step_d - seg_begin, U(step_u) reading slot step_u - seg_begin }
 template <int M2>
@@ -1963,6 +1756,17 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
   static const int dbg = getenv("WCT_JACOBI_DBG") ? atoi(getenv("WCT_JACOBI_DBG")) : 0;
   a.dbg = dbg;
   const unsigned grid = (has_d ? G.nmat * npair : 0) + (has_u ? G.nmat * ntask : 0);
+  if constexpr (M2 == 64) {
+    // round 4: pair problems resident in registers, 256 threads per pair problem and per update task (namespace r4);
+    // WCT_JACOBI_R4=0 selects the round-3 kernel (LDS-resident {S, Q} image, 1024 threads) -- an A-B switch
+    if (jacobi_r4_mode()) {
+      if (jacobi_r4_mode() == 2) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, false>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+      else hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+      if (has_d) G.par ^= 1;
+      if (has_u) G.cur ^= 1;
+      return;
+    }
+  }
   hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
 #ifdef JACOBI_TS
   if (has_d && !first && step_d >= 0 && M2 == 64) {
