@@ -149,6 +149,7 @@ void run_block(int nt, int bx, F fn) {
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / sqrtf(x))
 #define __builtin_amdgcn_readfirstlane(x) emul::readfirstlane(x)
+#define __builtin_amdgcn_readlane(x, l) emul::shfl_i((x), (l))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_update_dpp(o, s, c, rm, bm, bc) emul::update_dpp((o), (s), (c), (rm), (bm), (bc))
 #define __builtin_amdgcn_ds_bpermute(addr, v) emul::shfl_i((v), (addr) >> 2)

@@ -12,6 +12,9 @@ namespace emul { thread_local Idx tidx; thread_local Idx bidx; thread_local Bloc
 #include <stdio.h>
 #include <stdlib.h>
 #include "../../wct_tf_amd/csrc/jacobi_dev.h"
+#ifndef EMUL_VAR
+#define EMUL_VAR 1              // 1: strips (the shipped variant), 0: 2 x 2 patches
+#endif
 
 static int failures = 0;
 static void check(const char* what, double err, double tol) {
@@ -56,10 +59,16 @@ static void rot(double app, double aqq, double apq, double& c, double& s) {
   if ((tau >= 0) != (apq >= 0)) t = -t;
   c = 1.0 / sqrt(1 + t * t); s = c * t;
 }
+static double ref_offmax = 0;       // largest |a_pq| / sqrt(a_pp a_qq) over the pivots of sets 0 .. 32 of all pair problems
 static void reference_cross(const double* S0, double* S, double* Q) {
   std::vector<double> J(FR), T(FR);
   for (int i = 0; i < FR; ++i) { S[i] = S0[i]; Q[i] = (i / M2 == i % M2); }
-  for (int s = 0; s < B; ++s) {
+  for (int s = 0; s <= B; ++s) {
+    for (int k = 0; k < B; ++k) {
+      const int p = k, q = B + (k + s) % B;
+      ref_offmax = std::max(ref_offmax, std::min(1.0, fabs(S[p * M2 + q]) / sqrt(fabs(S[p * M2 + p] * S[q * M2 + q]))));
+    }
+    if (s == B) break;
     for (int i = 0; i < FR; ++i) J[i] = (i / M2 == i % M2);
     for (int k = 0; k < B; ++k) {
       const int p = k, q = B + (k + s) % B;
@@ -103,7 +112,7 @@ struct Solver {
   void run_d(const JacobiFusedArgs& a) {
     for (int g = 0; g < npair; ++g) {
       std::fill(lds.begin(), lds.end(), __builtin_nanf(""));          // LDS is not initialised on the device either
-      emul::run_block(r4::NT, g, [&](int) { r4::fused_d<M2>(a, 0, g, lds.data()); });
+      emul::run_block(r4::NT, g, [&](int) { r4::fused_d<M2, true, EMUL_VAR>(a, 0, g, lds.data()); });
     }
   }
   void run_u(const JacobiFusedArgs& a, bool with_v) {
@@ -161,6 +170,9 @@ int main() {
     check("cross step (first mode): rotation matrix Q vs the sequential sets", eQ, 2e-5);
     check("fp16 hi + lo fragments vs the fp32 rotation matrix", e16, 2e-6);
     check("(reference) cross-block mass after / before one cross step", red, 0.7);
+    const double offmax = __builtin_bit_cast(float, S.st.offmax), offsig = __builtin_bit_cast(float, S.st.offsig);
+    check("convergence statistics: largest relative pivot seen by the sets (offmax) vs the sequential sets", fabs(offmax - ref_offmax) / ref_offmax, 1e-4);
+    check("convergence statistics: the same over the significant pairs (floor 0: all of them)", fabs(offsig - ref_offmax) / ref_offmax, 1e-4);
   }
   // ---- launch 2: { D(step0 + 1) by look-ahead, U(step0) with V }
   JacobiFusedArgs a2 = S.args(0, 1, 0, 1, step0 + 1, step0, true, true, false, true);

@@ -14,10 +14,11 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason='ROCm clang++ not found')
-def test_r4_pair_problem_source_emulated_on_the_cpu(tmp_path):
+@pytest.mark.parametrize('variant', [1, 0], ids=['strips', 'patches'])
+def test_r4_pair_problem_source_emulated_on_the_cpu(tmp_path, variant):
     exe = str(tmp_path / 'jacobi_r4_emul')
     src = os.path.join(ROOT, 'tests', 'emul', 'jacobi_r4_emul.cpp')
-    subprocess.check_call([CLANG, '-std=c++17', '-O1', '-pthread', '-Wno-unused-value', '-o', exe, src])
+    subprocess.check_call([CLANG, '-std=c++17', '-O1', '-pthread', '-Wno-unused-value', '-DEMUL_VAR=%d' % variant, '-o', exe, src])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(out.stdout)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

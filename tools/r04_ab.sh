@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4, GPU box: A-B of the pair-problem kernels.  WCT_JACOBI_R4 = 0 (round 3: LDS image, 1024 threads) | 1 (registers,
-# 256 threads, DPP partner diagonal) | 2 (the same, partner diagonal through ds_bpermute).
+# 256 threads, 1 x W strips) | 2 (registers, 2 x 2 patches).
 # usage (gpurun): bash tools/r04_ab.sh
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -16,8 +16,7 @@ import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('batch %3d: %.1f frames/s, %.2f ms/step; jacobi %.2f ms, conv3x3 %.2f, apply %.2f, cov %.2f; sweeps %s' % (l['config']['global_batch'], l['value'], l['ms_per_step'], l['breakdown_ms_per_step']['jacobi'], l['breakdown_ms_per_step']['conv3x3'], l['breakdown_ms_per_step']['wct_apply'], l['breakdown_ms_per_step']['wct_cov'], {k:v['mean'] for k,v in l['eigensolver']['sweeps'].items()}))" >> $OUT 2>&1
   done
-  TAG="R4=$R4" timeout 300 python tools/r03_eig_time.py >> $OUT 2>&1
 done
 unset WCT_JACOBI_R4
-( timeout 900 python -m pytest tests/test_gpu_pipeline.py -x -q -k "gpus2 or bench_cli" 2>&1 | tail -4 ) >> $OUT
+bash tools/r04_ts.sh >> $OUT 2>&1
 cat $OUT

@@ -6,6 +6,9 @@
 #pragma once
 #include <type_traits>
 #include <utility>
+#ifndef JTS
+#define JTS(slot) do {} while (0)       // phase stamps of the -DJACOBI_TS build (wct.hip defines the real one)
+#endif
 
 struct JacobiState {
   unsigned int offmax;   // max |a_pq|/sqrt(a_pp a_qq) over the pairs rotated this sweep (float bits)
@@ -421,8 +424,220 @@ __device__ __forceinline__ void cross_sets(Patch& R, unsigned char* xb, const fl
   if (PWAVE) __builtin_amdgcn_s_setprio(0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Strips: the same register-resident pair problem with an UNEVEN split of the cells, written after the first
+// measurements of the 2 x 2 patches (profiles/r04_jacobi_ts.txt): with one wave per SIMD a set costs what the LONGEST
+// wave's instruction stream costs, and that was wave 0 -- four cells per lane like everybody else PLUS the pivot work
+// (two rotations per pivot lane, closed-form diagonals, statistics): 215 instructions against 115.  Here a lane owns a
+// 1 x W strip of cells (k, d0 .. d0 + W - 1): the two half-waves of wave 0 hold the columns d = 0 and d = 1 (W = 1),
+// the six half-waves of waves 1-3 five columns each.  Wave 0 rotates ONE cell per lane, its lanes 0..31 hold the 32
+// pivot cells (k, 0) and derive ONE rotation each; the convergence statistics of the rotations are evaluated after the
+// loop, by all lanes, from a log of the pivot blocks (see SX_LOG_B).  {S, Q} travel as float2 pairs so that the column
+// rotation is packed arithmetic (the same (c, s) acts on both halves); inside a strip the set s -> s+1 transition of
+// pq / Qpq / Qqq is a register rename (cell j uses the physical pair (j + s) mod W; the loop is unrolled lcm(W, 2) times).
+// Exchange per lane and set: 2 W + 3 floats -- qq[0..W) and qp[0..W) to lane k - 1 (qp[W-1] to the next strip's),
+// {pq, Qpq, Qqq} of the first column to the previous strip.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ constexpr int strip_w(int sg) { return sg < 2 ? 1 : 5; }
+__device__ constexpr int strip_d0(int sg) { return sg < 2 ? sg : 2 + 5 * (sg - 2); }
+// one exchange buffer: QQ4 f32x4[256] (qq of columns 0..3) | QP4 f32x4[256] (qp 0..3) | PQ f32x2[256] ({pq, Qpq} of column 0)
+// | E[3][256] floats (qq of column 4, qp of the LAST column, Qqq of column 0)
+constexpr int SX_QQ4 = 0, SX_QP4 = 4096, SX_PQ = 8192, SX_E = 10240, SX_BUF = 13312;
+constexpr int SX_CS = 2 * SX_BUF;              // CS[2][32] float2 (c, s)
+constexpr int SX_DUMMY = SX_CS + 2 * 256;      // absorbs the (c, s) / log stores of the lanes that own no pair
+constexpr int SX_BYTES = SX_DUMMY + 256 + 16;  // (the (c, s) stores add the ping-pong offset to the dummy address as well)
+// The S image (64 x 64 floats, in front of the exchange area) is dead while the sets run: it becomes the LOG of the pivot
+// blocks, entry (s, k) = float4 (pp, qq, pq, rotated?) the rotation of pair k prepared during set s was derived from.  The
+// convergence statistics of those 32 x 32 rotations are evaluated AFTER the loop by all 256 lanes, four entries each
+// (per set on one wave they cost that wave ~310 cycles of every set: three transcendentals and their selects --
+// profiles/r04_jacobi_ts.txt -- and made it the pole of the block).
+constexpr int SX_LOG_B = 32 * 32 * 16;
+
+template <int W> struct Strip { f32x2 Xpp[W], Xpq[W], Xqp[W], Xqq[W]; };    // {S, Q} pairs; Xpq / Xqq are PHYSICAL slots
+
+// one unrolled period of the set loop: sets s = 1, 2, .., LCM (mod LCM) of an iteration
+template <int LCM, class F, int... Is>
+__device__ __forceinline__ void run_period(F& body, std::integer_sequence<int, Is...>) {
+  (body(std::integral_constant<int, (Is + 1) % LCM>{}, std::true_type{}), ...);
+}
+
+template <int W, bool PWAVE, bool PK = true>
+__device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float* simg, int t, float floor_m, float& my_off, float& my_sig) {
+  constexpr int LCM = (W % 2) ? 2 * W : W;
+  static_assert(30 % LCM == 0, "sets 1..30 run as whole unrolled periods");
+  const int k = t & 31, sg = t >> 5;
+  const bool piv = PWAVE && sg == 0;                                   // lanes 0..31 of wave 0: pair k
+  const int dn = sg * 32 + ((k + 1) & 31);                             // lane (k + 1, same strip)
+  const int dl = ((sg + 7) & 7) * 32 + ((k + 1) & 31);                 // lane (k + 1, previous strip)
+  const int rt = ((sg + 1) & 7) * 32 + k;                              // lane (k, next strip)
+  int a_l[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) a_l[j] = SX_CS + ((k + strip_d0(sg) + j + 1) & 31) * 8;
+  const int a_k = SX_CS + k * 8;
+  const int a_csw = piv ? SX_CS + k * 8 : SX_DUMMY;
+  // log entry of this lane's pair for the set in progress (pivot lanes; the others store into the dummy slot)
+  unsigned char* logw = piv ? reinterpret_cast<unsigned char*>(simg) + k * 16 : xb + SX_DUMMY;
+  const int log_step = piv ? 32 * 16 : 0;
+  float ppk = 0.f, qqk = 0.f, pqk = 0.f;                               // pair k's pivot block (pivot lanes)
+  if (PWAVE) {
+    __builtin_amdgcn_s_setprio(2);                                     // the chain of a set runs through this wave
+    ppk = simg[k * 64 + k]; qqk = simg[(32 + k) * 64 + 32 + k]; pqk = simg[k * 64 + 32 + k];   // set 0 pairs k with 32 + k
+    float c, s, off, sig;
+    jacobi_rotation(ppk, qqk, pqk, floor_m, c, s, off, sig);
+    if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
+    f32x2 r; r[0] = c; r[1] = s;
+    *reinterpret_cast<f32x2*>(xb + a_csw) = r;
+  }
+  __syncthreads();                                                     // (the S image is free from here on)
+
+  auto take_rim = [&](auto SC) {                                       // the strip's rim for set S out of buffer S & 1
+    constexpr int S = decltype(SC)::value, LASTP = (W - 1 + S) % W;
+    const unsigned char* b = xb + (S & 1) * SX_BUF;
+    if constexpr (W == 5) {
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(b + SX_QQ4 + dn * 16);
+      const f32x4 p4 = *reinterpret_cast<const f32x4*>(b + SX_QP4 + dn * 16);
+      const float q5 = *reinterpret_cast<const float*>(b + SX_E + dn * 4);
+      const float pl = *reinterpret_cast<const float*>(b + SX_E + 1024 + dl * 4);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        R.Xqq[(j + S) % W][0] = j < 4 ? q4[j] : q5;
+        R.Xqp[j][0] = j == 0 ? pl : p4[j - 1];
+      }
+    } else {
+      R.Xqq[0][0] = *reinterpret_cast<const float*>(b + SX_QQ4 + dn * 16);
+      R.Xqp[0][0] = *reinterpret_cast<const float*>(b + SX_E + 1024 + dl * 4);
+    }
+    R.Xpq[LASTP] = *reinterpret_cast<const f32x2*>(b + SX_PQ + rt * 8);
+    R.Xqq[LASTP][1] = *reinterpret_cast<const float*>(b + SX_E + 2048 + rt * 4);
+  };
+
+#ifdef JACOBI_TS
+  unsigned long long busy = 0;
+#endif
+  auto body = [&](auto SC, auto INC) {
+    constexpr int S = decltype(SC)::value, CUR = S & 1, NX = CUR ^ 1;
+    constexpr bool IN = decltype(INC)::value;
+#ifdef JACOBI_TS
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+    const f32x2 rk = *reinterpret_cast<const f32x2*>(xb + CUR * 256 + a_k);
+    f32x2 rl[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) rl[j] = *reinterpret_cast<const f32x2*>(xb + CUR * 256 + a_l[j]);
+    if (IN) take_rim(SC);
+    const float ck = rk[0], sk = rk[1];
+    float nqq[W], nqp[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int P = (j + S) % W;
+      const float c = rl[j][0], s = rl[j][1];
+      // columns (pair l) on the {S, Q} pairs as packed arithmetic, then rows (pair k) on the S halves
+      f32x2 yp, yq, yqp, yqq;
+      if constexpr (PK) {
+        yp = c * R.Xpp[j] - s * R.Xpq[P];  yq = s * R.Xpp[j] + c * R.Xpq[P];
+        yqp = c * R.Xqp[j] - s * R.Xqq[P]; yqq = s * R.Xqp[j] + c * R.Xqq[P];
+      } else {                                                         // (A-B: the same element by element)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          yp[h] = c * R.Xpp[j][h] - s * R.Xpq[P][h];  yq[h] = s * R.Xpp[j][h] + c * R.Xpq[P][h];
+          yqp[h] = c * R.Xqp[j][h] - s * R.Xqq[P][h]; yqq[h] = s * R.Xqp[j][h] + c * R.Xqq[P][h];
+        }
+      }
+      f32x2 npp = yp, npq = yq;
+      npp[0] = ck * yp[0] - sk * yqp[0];  npq[0] = ck * yq[0] - sk * yqq[0];
+      nqp[j] = sk * yp[0] + ck * yqp[0];  nqq[j] = sk * yq[0] + ck * yqq[0];
+      R.Xpp[j] = npp;  R.Xpq[P] = npq;
+      R.Xqp[j][1] = yqp[1];  R.Xqq[P][1] = yqq[1];
+    }
+    constexpr int P0 = S % W;                                          // physical pair of column 0
+    if (PWAVE) {
+      // pair k after this set (closed form from registers); partner diagonal of the next set = the q diagonal pair k + 1
+      // has just produced (lane k + 1 of this half-wave); next pivot element = this lane's freshly rotated cell (k, 0)
+      const float c2 = ck * ck, s2 = sk * sk, cs2 = 2.f * ck * sk;
+      const float ppn = c2 * ppk - cs2 * pqk + s2 * qqk;
+      const float qqn = s2 * ppk + cs2 * pqk + c2 * qqk;
+      // (a DPP wave shift: lane i reads lane i + 1, the wrap-around lane 31 <- 0 patched with a v_readlane: no LDS round
+      // trip on the chain)
+      const int qi = __builtin_bit_cast(int, qqn);
+      const int shl = __builtin_amdgcn_update_dpp(qi, qi, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+      const int first = __builtin_amdgcn_readlane(qi, 0);
+      const float nb = __builtin_bit_cast(float, k == 31 ? first : shl);
+      ppk = ppn; qqk = nb; pqk = R.Xpq[P0][0];
+      float c, s;
+      const bool rot = jacobi_rotation_cs(ppk, qqk, pqk, c, s);
+      f32x2 r; r[0] = c; r[1] = s;
+      *reinterpret_cast<f32x2*>(xb + NX * 256 + a_csw) = r;
+      *reinterpret_cast<f32x4*>(logw) = f32x4{ppk, qqk, pqk, rot ? 1.f : 0.f};
+      logw += log_step;
+    }
+    unsigned char* b = xb + NX * SX_BUF;
+    if constexpr (W == 5) {
+      *reinterpret_cast<f32x4*>(b + SX_QQ4 + t * 16) = f32x4{nqq[0], nqq[1], nqq[2], nqq[3]};
+      *reinterpret_cast<f32x4*>(b + SX_QP4 + t * 16) = f32x4{nqp[0], nqp[1], nqp[2], nqp[3]};
+      *reinterpret_cast<float*>(b + SX_E + t * 4) = nqq[4];
+    } else {
+      *reinterpret_cast<float*>(b + SX_QQ4 + t * 16) = nqq[0];
+    }
+    *reinterpret_cast<float*>(b + SX_E + 1024 + t * 4) = nqp[W - 1];
+    *reinterpret_cast<f32x2*>(b + SX_PQ + t * 8) = R.Xpq[P0];
+    *reinterpret_cast<float*>(b + SX_E + 2048 + t * 4) = R.Xqq[P0][1];
+#ifdef JACOBI_TS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    busy += __builtin_amdgcn_s_memtime() - ts0;                        // release of the previous barrier -> arrival at this one
+#endif
+    __syncthreads();
+  };
+  body(std::integral_constant<int, 0>{}, std::false_type{});           // set 0: the strip is as loaded
+#pragma unroll 1
+  for (int it = 0; it < 30 / LCM; ++it) run_period<LCM>(body, std::make_integer_sequence<int, LCM>{});     // sets 1 .. 30
+  body(std::integral_constant<int, 31 % LCM>{}, std::true_type{});     // set 31
+  take_rim(std::integral_constant<int, 32 % LCM>{});                   // the arrangement of "set 32" = that of set 0
+  if (PWAVE) __builtin_amdgcn_s_setprio(0);
+  // the statistics of the 32 x 32 logged rotations (the last set's are those of a rotation that is never applied: the
+  // state of the pivots after the step), four per lane
+#pragma unroll
+  for (int i = 0; i < SX_LOG_B / 16 / NT; ++i) {
+    const f32x4 e = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(simg) + (t + i * NT) * 16);
+    float off, sig;
+    jacobi_rotation_stats(e[0], e[1], e[2], floor_m, e[3] != 0.f, off, sig);
+    my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig);
+  }
+#ifdef JACOBI_TS
+  if ((t & 63) == 0 && blockIdx.x < 8192) jac_busy[blockIdx.x * 4 + (t >> 6)] = busy;
+#endif
+}
+
+// gather -> sets -> scatter for the lanes of one wave (strip width W); contains the barriers of the set loop and one more
+template <int W, bool PWAVE, bool PK = true>
+__device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned char* xb, int t, float floor_m, float& my_off, float& my_sig) {
+  constexpr int M2 = 64, B = 32;
+  const int k = t & 31, sg = t >> 5;
+  Strip<W> R;
+  int la[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int l = (k + strip_d0(sg) + j + 1) & 31;
+    la[j] = l;
+    const float one = k == l ? 1.f : 0.f;
+    R.Xpp[j] = f32x2{simg[k * M2 + l], one};        R.Xpq[j] = f32x2{simg[k * M2 + B + l], 0.f};
+    R.Xqp[j] = f32x2{simg[(B + k) * M2 + l], 0.f};  R.Xqq[j] = f32x2{simg[(B + k) * M2 + B + l], one};
+  }
+  strip_sets<W, PWAVE, PK>(R, xb, simg, t, floor_m, my_off, my_sig);
+  __syncthreads();                                  // every lane has taken its last rim: the exchange area becomes the Q image
+  constexpr int LCM = (W % 2) ? 2 * W : W, SF = 32 % LCM;
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int l = la[j], P = (j + SF) % W;
+    simg[k * M2 + l] = R.Xpp[j][0];        simg[k * M2 + B + l] = R.Xpq[P][0];
+    simg[(B + k) * M2 + l] = R.Xqp[j][0];  simg[(B + k) * M2 + B + l] = R.Xqq[P][0];
+    qimg[k * M2 + l] = R.Xpp[j][1];        qimg[k * M2 + B + l] = R.Xpq[P][1];
+    qimg[(B + k) * M2 + l] = R.Xqp[j][1];  qimg[(B + k) * M2 + B + l] = R.Xqq[P][1];
+  }
+}
+
 // D part: the pair problem (bi, bj) of matrix m at outer step p.step_d -- 256 threads (jacobi_fused_d: 1024)
-template <int M2, bool DPP = true>
+// VAR: 0 = 2 x 2 patches (cross_sets), 1 = strips (strip_sets), 2 = strips with element-wise arithmetic (A-B)
+template <int M2, bool DPP = true, int VAR = 1>
 __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, float* jsm) {
   static_assert(M2 == 64, "the patch layout is written for 64 x 64 pair problems");
   constexpr int B = M2 / 2, NW = M2 / 16, FR = M2 * M2;
@@ -441,6 +656,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
   if (p.first) {
     if (p.st[m].done) return;
     floor_m = p.st[m].floor;
+    JTS(1);
     const float* Am = p.Pr + (size_t)m * C * C;
     for (int e = tid; e < FR; e += NT) {
       const int r = e / M2, c = e % M2;
@@ -502,6 +718,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     }
     if (p.st[m].done) return;                       // (block-uniform)
     floor_m = p.st[m].floor;
+    JTS(1);
     f32x4 crit = {0.f, 0.f, 0.f, 0.f};
     const int li = lane & 15, lq = lane >> 4;
     if (!same) {
@@ -510,6 +727,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) { Xs[xr[i] * (M2 + 1) + xc[i] + j] = xv[i][j]; Qdst[i][j * (B + 1)] = qv[i][j]; }
       __syncthreads();
+      JTS(2);
 #pragma unroll
       for (int jb = 0; jb < (B / 16) * NW / (NT / 64); ++jb) {          // W = Q_g1[:, h1]^T X   (B x M2): two tiles per wave
         const int job = wave * ((B / 16) * NW / (NT / 64)) + jb, tr = job / NW, tj = job % NW;
@@ -528,6 +746,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
           crit = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * tr + li) * (M2 + 1) + kk + lq], Q2s[(kk + lq) * (B + 1) + 16 * tc + li], crit, 0, 0, 0);
       }
       __syncthreads();                              // the staging area becomes the image
+      JTS(3);
     }
 #pragma unroll
     for (int i = 0; i < FR / NT; ++i) {
@@ -551,38 +770,49 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     __syncthreads();
   }
   float* Qimg = jsm + FR;                           // [M2][M2] floats (cross steps: epilogue only)
+  JTS(4);
   if (p.step_d >= 0) {
+    if constexpr (VAR >= 1) {
+      // ---- strips: gather, 32 sets, scatter, by wave (the three branches execute the same barriers)
+      unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + FR);
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      if (wv == 0) strip_wave<1, true, VAR == 1>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
+      else strip_wave<5, false, VAR == 1>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
+      JTS(5);
+    } else {
     // ---- the patch out of the image, 32 sets, the patch back into the S and Q images
-    const int I = tid & 15, Dd = tid >> 4;
-    Patch R;
-    int ka[2], la[2][2];
+      const int I = tid & 15, Dd = tid >> 4;
+      Patch R;
+      int ka[2], la[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ka[i] = 2 * I + i;
+      for (int i = 0; i < 2; ++i) {
+        ka[i] = 2 * I + i;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int k = ka[i], l = (k + 2 * Dd + j + 1) & 31;
-        la[i][j] = l;
-        R.pp[i][j] = Simg[k * M2 + l];        R.pq[i][j] = Simg[k * M2 + B + l];
-        R.qp[i][j] = Simg[(B + k) * M2 + l];  R.qq[i][j] = Simg[(B + k) * M2 + B + l];
-        R.Qpp[i][j] = k == l ? 1.f : 0.f;  R.Qqq[i][j] = R.Qpp[i][j];
-        R.Qpq[i][j] = 0.f;  R.Qqp[i][j] = 0.f;
+        for (int j = 0; j < 2; ++j) {
+          const int k = ka[i], l = (k + 2 * Dd + j + 1) & 31;
+          la[i][j] = l;
+          R.pp[i][j] = Simg[k * M2 + l];        R.pq[i][j] = Simg[k * M2 + B + l];
+          R.qp[i][j] = Simg[(B + k) * M2 + l];  R.qq[i][j] = Simg[(B + k) * M2 + B + l];
+          R.Qpp[i][j] = k == l ? 1.f : 0.f;  R.Qqq[i][j] = R.Qpp[i][j];
+          R.Qpq[i][j] = 0.f;  R.Qqp[i][j] = 0.f;
+        }
       }
+      unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + FR);
+      if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) cross_sets<true, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
+      else cross_sets<false, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
+      JTS(5);
+      __syncthreads();                                // every lane has taken its last rim: the exchange area becomes the Q image
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = ka[i], l = la[i][j];
+          Simg[k * M2 + l] = R.pp[i][j];        Simg[k * M2 + B + l] = R.pq[i][j];
+          Simg[(B + k) * M2 + l] = R.qp[i][j];  Simg[(B + k) * M2 + B + l] = R.qq[i][j];
+          Qimg[k * M2 + l] = R.Qpp[i][j];       Qimg[k * M2 + B + l] = R.Qpq[i][j];
+          Qimg[(B + k) * M2 + l] = R.Qqp[i][j]; Qimg[(B + k) * M2 + B + l] = R.Qqq[i][j];
+        }
     }
-    unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + FR);
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) cross_sets<true, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
-    else cross_sets<false, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
-    __syncthreads();                                // every lane has taken its last rim: the exchange area becomes the Q image
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int k = ka[i], l = la[i][j];
-        Simg[k * M2 + l] = R.pp[i][j];        Simg[k * M2 + B + l] = R.pq[i][j];
-        Simg[(B + k) * M2 + l] = R.qp[i][j];  Simg[(B + k) * M2 + B + l] = R.qq[i][j];
-        Qimg[k * M2 + l] = R.Qpp[i][j];       Qimg[k * M2 + B + l] = R.Qpq[i][j];
-        Qimg[(B + k) * M2 + l] = R.Qqp[i][j]; Qimg[(B + k) * M2 + B + l] = R.Qqq[i][j];
-      }
     __syncthreads();
     constexpr int NCH = M2 / 32;
 #pragma unroll
@@ -640,6 +870,11 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     if (my_sig > 0.f) atomicMax(&p.st[m].offsig, __float_as_uint(my_sig));
     if (my_dm > 0.f && my_dm < 3.0e38f) atomicMax(&p.st[m].dmax, __float_as_uint(my_dm));
   }
+  JTS(6);
+#ifdef JACOBI_TS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  JTS(7);
+#endif
 }
 
 // U part: one task of the tile update (see jacobi_fused_u) by 256 threads: a wave owns a 16-row strip of the 64 x 64 tile

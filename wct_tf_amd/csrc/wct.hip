@@ -508,6 +508,13 @@ __global__ void cov_finish_kernel(const float* partial, const float* scale, floa
 //   fp32 MFMA (jacobi_update_kernel).  Two launches per step, C/B-1 steps per sweep.
 //   A per-matrix `done` flag turns later launches into no-ops.
 // ---------------------------------------------------------------------------
+#ifdef JACOBI_TS
+__device__ unsigned long long jac_ts[8192 * 10];
+__device__ unsigned long long jac_busy[8192 * 4];      // strip_sets: cycles each wave spent between the barriers of its 32 sets
+#define JTS(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { jac_ts[blockIdx.x * 10 + (slot)] = __builtin_amdgcn_s_memtime(); if ((slot) == 0) jac_ts[blockIdx.x * 10 + 8] = wall_clock64(); if ((slot) == 7) jac_ts[blockIdx.x * 10 + 9] = wall_clock64(); } } while (0)
+#else
+#define JTS(slot) do {} while (0)
+#endif
 #include "jacobi_dev.h"
 
 
@@ -892,12 +899,6 @@ __global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(floa
 // ---------------------------------------------------------------------------
 // Phase timing build (-DJACOBI_TS, tools/r03_jacobi_ts.sh): lane 0 of every pair-problem block stamps s_memtime at its
 // phase boundaries; the launcher prints per-launch means.  Compiled out of the product.
-#ifdef JACOBI_TS
-__device__ unsigned long long jac_ts[8192 * 10];
-#define JTS(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { jac_ts[blockIdx.x * 10 + (slot)] = __builtin_amdgcn_s_memtime(); if ((slot) == 0) jac_ts[blockIdx.x * 10 + 8] = wall_clock64(); if ((slot) == 7) jac_ts[blockIdx.x * 10 + 9] = wall_clock64(); } } while (0)
-#else
-#define JTS(slot) do {} while (0)
-#endif
 
 template <int M2>
 static size_t jacobi_fused_lds(int has_d, int has_u, int first, int step_d) {
@@ -1221,7 +1222,7 @@ static size_t fused_lds(int has_d, int has_u, int first, int step_d) {
   if (has_d) {
     if (step_d < 0) need = jacobi_diag_lds<M2>(-1, true);                               // intra sets: two {S, Q} images
     else {
-      need = (size_t)M2 * M2 * sizeof(float) + XCHG_B;                                  // S image, exchange area
+      need = (size_t)M2 * M2 * sizeof(float) + std::max(XCHG_B, SX_BYTES);              // S image, exchange area
       need = std::max(need, (size_t)2 * M2 * M2 * sizeof(float));                       // S and Q images of the epilogue
       if (!first) need = std::max(need, (size_t)(M2 * (M2 + 1) + 2 * M2 * (B + 1) + B * (M2 + 1)) * sizeof(float));
     }
@@ -1233,7 +1234,7 @@ static size_t fused_lds(int has_d, int has_u, int first, int step_d) {
 
 
 // grid: [nmat * npair pair problems (if has_d)] [ntask * nmat update tasks, task-major (if has_u)]; 256 threads
-template <int M2, bool DPP>
+template <int M2, bool DPP, int VAR>
 __global__ __launch_bounds__(r4::NT, 3) void jacobi_fused4_kernel(JacobiFusedArgs p) {
   extern __shared__ __attribute__((aligned(16))) float jsm[];
   constexpr int B = M2 / 2;
@@ -1242,7 +1243,8 @@ __global__ __launch_bounds__(r4::NT, 3) void jacobi_fused4_kernel(JacobiFusedArg
   int b = blockIdx.x;
   if (b < n_d) {
     const int m = b / npair, g = b % npair;
-    r4::fused_d<M2, DPP>(p, m, g, jsm);
+    JTS(0);
+    r4::fused_d<M2, DPP, VAR>(p, m, g, jsm);
   } else {
     b -= n_d;
     const int task = b / p.nmat, m = b % p.nmat;
@@ -1756,18 +1758,16 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
   static const int dbg = getenv("WCT_JACOBI_DBG") ? atoi(getenv("WCT_JACOBI_DBG")) : 0;
   a.dbg = dbg;
   const unsigned grid = (has_d ? G.nmat * npair : 0) + (has_u ? G.nmat * ntask : 0);
+  // round 4 (M2 = 64): pair problems resident in registers, 256 threads per pair problem and per update task (namespace
+  // r4): 1 x W strips (default).  A-B switches: WCT_JACOBI_R4=0 selects the round-3 kernel (LDS-resident {S, Q} image, 1024
+  // threads), =2 the register kernel with 2 x 2 patches
+  const int r4m = M2 == 64 ? jacobi_r4_mode() : 0;
   if constexpr (M2 == 64) {
-    // round 4: pair problems resident in registers, 256 threads per pair problem and per update task (namespace r4);
-    // WCT_JACOBI_R4=0 selects the round-3 kernel (LDS-resident {S, Q} image, 1024 threads) -- an A-B switch
-    if (jacobi_r4_mode()) {
-      if (jacobi_r4_mode() == 2) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, false>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
-      else hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
-      if (has_d) G.par ^= 1;
-      if (has_u) G.cur ^= 1;
-      return;
-    }
+    if (r4m == 2) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true, 0>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+    else if (r4m == 3) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true, 2>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+    else if (r4m) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true, 1>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
   }
-  hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+  if (!r4m) hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
 #ifdef JACOBI_TS
   if (has_d && !first && step_d >= 0 && M2 == 64) {
     static int nlaunch = 0, last_nmat = 0;
@@ -1786,8 +1786,9 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
     }
     if (nlaunch == 0) {
       int occ = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, jacobi_fused_kernel<M2>, NT, jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
-      printf("jacobi_ts: occupancy API says %d blocks of %d threads per CU with %zu B of LDS\n", occ, NT, jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
+      if (r4m) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, jacobi_fused4_kernel<64, true, 1>, r4::NT, r4::fused_lds<64>(has_d, has_u, first, step_d));
+      else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, jacobi_fused_kernel<M2>, NT, jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
+      printf("jacobi_ts: occupancy API says %d blocks of %d threads per CU with %zu B of LDS\n", occ, r4m ? r4::NT : NT, r4m ? r4::fused_lds<64>(has_d, has_u, first, step_d) : jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
     }
     span += (double)(hi - lo);
     if (nlaunch == 40) {
@@ -1796,6 +1797,16 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
       std::sort(st0.begin(), st0.end()); std::sort(en0.begin(), en0.end());
       printf("jacobi_ts nmat %d launch 40: block start offsets (10 ns ticks) p0 %llu p25 %llu p50 %llu p75 %llu p90 %llu p100 %llu | end offsets p0 %llu p50 %llu p100 %llu\n", G.nmat,
              st0[0], st0[nb / 4], st0[nb / 2], st0[3 * nb / 4], st0[9 * nb / 10], st0[nb - 1], en0[0], en0[nb / 2], en0[nb - 1]);
+    }
+    if (r4m == 1 || r4m == 3) {
+      static unsigned long long hb[8192 * 4];
+      static double bs[4] = {0, 0, 0, 0};
+      if (nlaunch == 0) for (double& v : bs) v = 0;
+      (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(jac_busy), sizeof(hb));
+      for (int i = 0; i < nb; ++i) for (int w = 0; w < 4; ++w) bs[w] += (double)hb[i * 4 + w] / nb;
+      if ((nlaunch + 1) % 32 == 0)
+        printf("jacobi_ts nmat %d: cycles between barrier release and next arrival, summed over the 32 sets, by wave: pivots %.0f | strips %.0f %.0f %.0f\n",
+               G.nmat, bs[0] / (nlaunch + 1), bs[1] / (nlaunch + 1), bs[2] / (nlaunch + 1), bs[3] / (nlaunch + 1));
     }
     if (++nlaunch % 32 == 0) {
       printf("jacobi_ts nmat %d (%d launches): state %.0f | loads->LDS %.0f | crit %.0f | image %.0f | sets %.0f | stores issued %.0f | drained %.0f | first start -> last end %.0f wall-clock ticks (100 MHz) (others: s_memtime ticks)\n",
