@@ -115,6 +115,21 @@ def hard512_inputs(case):
     return synthetic_features_exact(sc, c, h, w, 4.0), synthetic_features_exact(ss, c, h, w, 4.0)
 
 
+# A 512-channel spectrum that runs THROUGH the 1e-5 cut-off: 8 decades over 512 channels at N = 4096
+# put ~64 eigenvalues in every decade, 3.7 % apart -- inside the fp32 noise of the reference's own SVD (eps ||A|| ~ 1e-6
+# against eigenvalues of 1e-5), so WHICH of the borderline modes the reference keeps is decided by its rounding.  The
+# fixture therefore stores, beside the digest of the reference's output, the kept counts (kc, ks) that reproduce it
+# (searched with the oracle's test-only `keep` override around the float64 counts) and the float64 counts themselves;
+# tests judge an implementation by the band of kept counts, like the fuzz tests do for C <= 128.
+CROSS512_CASE = ('c512_cross_cutoff_n4096', 512, 64, 64, 0.8, 7304, 7404)
+
+
+def cross512_inputs():
+    name, c, h, w, alpha, sc, ss = CROSS512_CASE
+    return (graded_features_exact(sc, c, h * w, 8.0, 1.8).reshape(1, h, w, c),
+            graded_features_exact(ss, c, h * w, 8.0, 1.5).reshape(1, h, w, c))
+
+
 # wct_tf (ops.py:24-90, the transform the live graph runs) pinned through the reference's own code: TensorFlow cannot
 # be imported, but wct_np(content, style, alpha, eps=0) differs from wct_tf only by (1) the content mean that wct_tf
 # restores in the blend (ops.py:83 vs :133) and (2) the 1e-8 wct_tf adds to the covariance diagonals (ops.py:45,50),
@@ -222,6 +237,33 @@ def main():
         blob[name + '/content_eig_max_min_kept'] = np.array([ev.max(), ev[ev > 1e-5].min(), (ev > 1e-5).sum()])
         print(name, 'content eigenvalues %.2e .. %.2e kept %d' % (ev.max(), max(ev.min(), 1e-30), (ev > 1e-5).sum()))
     np.savez_compressed(os.path.join(OUT, 'wct_np_hard512.npz'), **blob)
+
+    # ---- a 512-channel spectrum through the cut-off: reference output digest + the kept counts that reproduce it ----
+    from oracle import wct_oracle
+    name, c, h, w, alpha = CROSS512_CASE[:5]
+    fc, fs = cross512_inputs()
+    out = ref_wct_np(fc, fs, alpha)
+    o = out.reshape(h * w, c)
+    rows, signs = digest_selectors(CROSS512_CASE)
+    blob = {name + '/rows': o[rows], name + '/sketch': signs @ o.astype(np.float64), name + '/mean': o.astype(np.float64).mean(0),
+            name + '/sq': (o.astype(np.float64) ** 2).mean(0), name + '/in_probe': np.stack([in_probe(fc), in_probe(fs)])}
+    k64, near = [], []
+    for f in (fc, fs):
+        ev = np.linalg.eigvalsh(np.cov(f.reshape(-1, c).astype(np.float64).T))
+        k64.append(int((ev > 1e-5).sum()))
+        near.append(int(((ev > 1e-6) & (ev < 1e-4)).sum()))
+    best, best_err = None, 1e9
+    for kc in range(k64[0] - 4, k64[0] + 5):
+        for ks in range(k64[1] - 4, k64[1] + 5):
+            e = np.linalg.norm(wct_oracle.wct_np(fc, fs, alpha, keep=(kc, ks))[0].reshape(h * w, c)[rows] - o[rows]) / np.linalg.norm(o[rows])
+            if e < best_err:
+                best, best_err = (kc, ks), e
+    blob[name + '/kept_float64'] = np.array(k64)
+    blob[name + '/kept_reference'] = np.array(best)
+    blob[name + '/within_a_decade_of_cutoff'] = np.array(near)
+    print(name, 'float64 kept', k64, 'eigenvalues within a decade of the cut-off', near, 'reference output reproduced by keep =', best, 'rel %.2e' % best_err)
+    assert min(near) >= 20 and best_err < 1e-3
+    np.savez_compressed(os.path.join(OUT, 'wct_np_cross512.npz'), **blob)
 
     # ---- wct_tf through the reference's wct_np(eps=0) ----
     blob = {}

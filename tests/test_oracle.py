@@ -71,6 +71,28 @@ def test_wct_np_matches_reference_on_hard_512_channel_spectra():
         print(case[0], z[case[0] + '/content_eig_max_min_kept'], check_against_size_digest(z, case[:7], out, 1e-5))
 
 
+def test_wct_np_matches_reference_on_a_512_channel_spectrum_through_the_cutoff():
+    """tests/golden/wct_np_cross512.npz: the reference's own wct_np on a 512-channel covariance whose eigenvalues run
+    THROUGH the 1e-5 cut-off, ~125 of them within a decade of it (oracle/make_golden.py CROSS512_CASE).  The restatement
+    reproduces the reference's output -- including its keep/drop decisions on the borderline modes, which are inside the
+    fp32 noise of the SVD -- and the recorded kept counts are the ones its own arithmetic arrives at."""
+    from oracle.make_golden import CROSS512_CASE, cross512_inputs, in_probe
+    from conftest import check_against_size_digest
+    z = np.load(os.path.join(GOLDEN, 'wct_np_cross512.npz'))
+    name, c, h, w, alpha = CROSS512_CASE[:5]
+    fc, fs = cross512_inputs()
+    assert np.allclose(np.stack([in_probe(fc), in_probe(fs)]), z[name + '/in_probe'], rtol=1e-6)
+    assert min(z[name + '/within_a_decade_of_cutoff']) >= 20
+    out = oracle.wct_np(fc, fs, alpha)
+    check_against_size_digest(z, CROSS512_CASE, out, 1e-4)
+    kept = tuple(int(k) for k in z[name + '/kept_reference'])
+    assert rel_err(oracle.wct_np(fc, fs, alpha, keep=kept), out) < 1e-6           # the default run IS the recorded counts
+    # what a borderline mode is worth on this input: 1.4e-4 (content side) / 3.8e-4 (style side) of the output per mode --
+    # three style modes off is most of the 1e-3 budget, ten are beyond it
+    assert rel_err(oracle.wct_np(fc, fs, alpha, keep=(kept[0], kept[1] + 3)), out) > 4e-4
+    assert rel_err(oracle.wct_np(fc, fs, alpha, keep=(kept[0], kept[1] - 10)), out) > 1e-3
+
+
 def test_wct_tf_is_pinned_by_the_reference_wct_np_without_eps():
     """ops.py:24-90 cannot run (TensorFlow), but ops.py:92-140 can: wct_np(c, s, alpha, eps=0) + (1 - alpha) mc is
     wct_tf up to the 1e-8 that wct_tf adds to the covariance diagonals (ops.py:45,50), i.e. up to 0.5e-8 / lambda_min
