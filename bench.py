@@ -155,9 +155,36 @@ def cpu_baseline(size, weights, alpha):
             # part (i), the reference's transform in NumPy (five whiten-colour transforms per frame, LAPACK
             # SVD), reported separately from part (ii), the torch-CPU stand-in for the CPU-TF conv stack
             'transform_s': med_t, 'conv_standin_s': med - med_t,
-            'sample': '1 warm-up + median of 5 frames %dx%d, 5-level, alpha %.1f: NumPy transform (restatement of the reference\'s '
+            'sample': '1 warm-up + median of 5 frames %dx%d, 5-level, alpha %.1f: NumPy transform (oracle.wct_tf, the RESTATEMENT of the reference\'s '
                       'wct_tf/wct_np, LAPACK SVD) + torch-CPU stand-in for the CPU-TF conv stack; %.2f s per frame '
                       '(min %.2f, max %.2f)' % (size, size, alpha, med, min(times), max(times))}
+
+
+def real_image_leg(ctx, alpha, n=10):
+    """The headline's spectra are those of synthetic noise images; this leg puts a PHOTOGRAPH next to them: the reference's
+    sample photo (samples/gilbert.jpg resampled to 512 x 512: tests/golden/gilbert_512.npz, written by oracle/make_golden.py)
+    as content and its mirror image as style through the five levels, batch 1, resident inputs -- sweeps per channel
+    count, eigensolver ms per frame, frames/s.  (The weights stay the synthetic He-normal stand-in: no VGG weights offline.)"""
+    path = os.path.join(ROOT, 'tests', 'golden', 'gilbert_512.npz')
+    if not os.path.exists(path):
+        return None
+    img = np.load(path)['image']
+    c, s = np.ascontiguousarray(img), np.ascontiguousarray(img[:, ::-1])
+    for _ in range(2):
+        ctx.stylize(c, s, LEVELS, alpha=alpha)
+    ctx.eig_stats()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = ctx.stylize(c, s, LEVELS, alpha=alpha)
+    dt = (time.perf_counter() - t0) / n
+    ctx.prof_enable(False)
+    prof, eig = ctx.prof_read(), ctx.eig_stats()
+    return {'image': 'samples/gilbert.jpg resampled to 512x512 (content) and its mirror image (style), 5 levels, alpha %.1f, batch 1' % alpha,
+            'frames_per_s': 1.0 / dt, 'ms_per_frame': 1e3 * dt, 'eigensolver_ms_per_frame': prof['jacobi']['ms'] / n,
+            'sweeps': {str(cc): {'mean': v['sweeps'] / max(1, v['matrices']), 'max': v['max_sweeps']} for cc, v in sorted(eig.items())},
+            'output_std': float(np.asarray(out, np.float64).std()),
+            'note': 'host uint8 in -> host uint8 out like latency_ms; synthetic He-normal weights'}
 
 
 def latency_leg(ctx, size, alpha, n=20):
@@ -392,6 +419,10 @@ def main():
             line.update(latency_leg(ctx, S, args.alpha))
             if 'eigensolver' in line:
                 line['eigensolver']['hard_spectrum'] = hard_spectrum_leg(ctx)
+            if S == 512:
+                real = real_image_leg(ctx, args.alpha)
+                if real is not None:
+                    line['real_image'] = real
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(S, weights, args.alpha)
         print(json.dumps(line), flush=True)

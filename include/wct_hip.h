@@ -33,7 +33,8 @@ typedef struct wct_ctx wct_ctx;
 enum wct_status { WCT_STATUS_OK = 0, WCT_STATUS_HIP = -1, WCT_STATUS_ARG = -2,
                   WCT_STATUS_STATE = -3, WCT_STATUS_NOMEM = -4,
                   /* An eigendecomposition behind the call (the stand-in for tf.svd / np.linalg.svd, ops.py:53-65,110,123)
-                   * did not converge within its sweep budget (12 sweeps; 7-8 are typical at C = 512), or met NaN/Inf
+                   * did not converge within its sweep budget (16 sweeps; 4-6 are typical at C = 512, 7-10 on graded
+                   * rank-deficient spectra; the test hook WCT_JACOBI_MAX_SWEEPS can only lower it), or met NaN/Inf
                    * in a covariance.  The outputs of the call ARE written (best effort, as LAPACK does with info > 0)
                    * but must not be trusted; the reference's own worry at this spot is ops.py:57-65.  Reported by the
                    * blocking calls themselves and, for wct_stylize_batch_dev (asynchronous), by the next wct_sync. */

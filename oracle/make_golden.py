@@ -179,8 +179,17 @@ def gilbert_fixture():
     return np.ascontiguousarray(a), np.ascontiguousarray(b)
 
 
+def gilbert_512():
+    """samples/gilbert.jpg (481 x 525) resampled to 512 x 512 (Pillow, bicubic): the real-image leg of bench.py (VERDICT r3
+    item 6d) -- a photograph's spectrum beside the synthetic frames'.  An input sample, not source."""
+    from PIL import Image
+    img = Image.open(os.path.join(REF, 'samples', 'gilbert.jpg')).convert('RGB')
+    return np.ascontiguousarray(np.asarray(img.resize((512, 512), Image.BICUBIC)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, 'gilbert_512.npz'), image=gilbert_512())
     ref_wct_np = lift_function(os.path.join(REF, 'ops.py'), 'wct_np')
     ref_wct_np(np.zeros((1, 2, 2, 32), np.float32) + np.arange(32, dtype=np.float32), np.ones((1, 2, 2, 32), np.float32), 0.5, 0.0)   # signature: (content, style, alpha, eps)
 

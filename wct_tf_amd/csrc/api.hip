@@ -163,7 +163,7 @@ extern "C" int wct_create(int device, wct_ctx** out) {
     return WCT_ERR_HIP;
   }
   for (int i = 0; i < WCT_EIG_WORDS; ++i) c->eig_fail[i] = 0;
-  if (const char* e = getenv("WCT_EIG_GROUPS")) { int n = atoi(e); c->nside = n < 1 ? 0 : (n > 4 ? 3 : n - 1); }
+  { const int n = tune_int("WCT_EIG_GROUPS", -1); if (n >= 0) c->nside = n < 1 ? 0 : (n > 4 ? 3 : n - 1); }
   *out = c;
   return WCT_OK;
 }
@@ -539,7 +539,7 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
   // into their epilogue; WCT_FUSE_POOL=0 runs the separate pool kernel instead)
   static const int seq_tap[12] = {0, 2, 0, 3, 0, 0, 0, 4, 0, 0, 0, 5};
   static const int pool_after[12] = {1, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 0};
-  static const int fuse_pool = getenv("WCT_FUSE_POOL") ? atoi(getenv("WCT_FUSE_POOL")) : 1;
+  static const int fuse_pool = tune_int("WCT_FUSE_POOL", 1);
   int h = H, w = W;
   for (int i = 0; i < 12; ++i) {
     const ConvLayer& l = c->enc[i];

@@ -39,6 +39,22 @@ void wct_set_error(const char* fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// A-B / tuning switches.  In the product build they are constants: a stray environment variable must never change the
+// numerics of a library whose contract is bit-reproducible output.  Only a -DWCT_TUNING build (tools/, experiments on the
+// GPU box) reads them from the environment.  Two documented TEST hooks stay live in every build, both safe by
+// construction: WCT_JACOBI_MAX_SWEEPS can only LOWER the sweep budget (the solve then fails loudly, never silently), and
+// WCT_FUSE_STATS=0 selects a path whose output is bit-identical (asserted by tests/test_gpu_pipeline.py).
+#ifdef WCT_TUNING
+#include <stdlib.h>
+static inline int tune_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline float tune_float(const char* name, float dflt) { const char* e = getenv(name); return e ? (float)atof(e) : dflt; }
+static inline bool tune_set(const char* name) { return getenv(name) != nullptr; }
+#else
+static inline int tune_int(const char*, int dflt) { return dflt; }
+static inline float tune_float(const char*, float dflt) { return dflt; }
+static inline bool tune_set(const char*) { return false; }
+#endif
+
 // ---- conv.hip -------------------------------------------------------------
 struct ConvArgs {
   const half_t* x;     // [B][Hin][Win][Cin] fp16 NHWC

@@ -410,7 +410,7 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK(!a.usum || (a.y32 && a.umax && a.relu && a.W % 16 == 0));
   ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
-  static const int force = getenv("WCT_CONV_CFG") ? atoi(getenv("WCT_CONV_CFG")) : 0;   // tuning switch
+  static const int force = tune_int("WCT_CONV_CFG", 0);   // tuning switch
   if (force == 1 && a.Cout % 128 == 0) return launch_conv_cfg<16, 128, 2, 2>(a, s);
   if (force == 2) return launch_conv_cfg<32, 64, 4, 1>(a, s);
   if (force == 3) return launch_conv_cfg<16, 64, 4, 1>(a, s);

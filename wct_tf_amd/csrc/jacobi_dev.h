@@ -23,7 +23,7 @@ struct JacobiState {
   float r2l;             // the lenient one (what the final status is judged by)
   int pad;               // look-ahead path: the buffer (0: A, 1: the second one) that held the matrix when it was declared done
   int seg_stop;          // number of launch segments whose rotations belong to this matrix (INT_MAX while it is still rotating)
-  int pad2;
+  int pad2;              // 1: a diagonal within half a decade of the 1e-5 cut-off at the last residual measurement (first-order completion only)
 };
 constexpr int JACOBI_RESID_CHUNKS = 16;
 constexpr float JACOBI_SIG_FLOOR = 1e-4f;

@@ -516,80 +516,13 @@ __device__ unsigned long long jac_busy[8192 * 4];      // strip_sets: cycles eac
 #define JTS(slot) do {} while (0)
 #endif
 #include "jacobi_dev.h"
+#ifdef WCT_TUNING
+#define JDBG(p) ((p).dbg)       // WCT_JACOBI_DBG timing experiments (results invalid): tuning builds only
+#else
+#define JDBG(p) 0
+#endif
 
 
-
-// The cross sweep (one outer step: N/2 rotation sets over the (N/2)^2 pairs (i in I, j in J)), written for
-// instruction count: it is issue-bound (16 waves per block, two blocks per CU).  Relative to the generic
-// jacobi_sets: p indices are fixed per thread and q indices advance by one per set, so the byte offsets are
-// carried incrementally; the loop is unrolled over the two ping-pong images so that the image, D and O
-// selectors are immediates of the LDS instructions; the owner-only D/O updates are unconditional stores to
-// the real slot or to a dummy slot (no exec-mask branches); the rotation is branch-free; scalar FMAs only
-// (hipcc's packed-f32 form of the same arithmetic spent 9 v_mov per set on operand assembly).
-// 149 -> ~100 instructions per set.
-template <int N>
-__device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned char* dob, int t, float floor_m, float& my_off, float& my_sig) {
-  constexpr int NP = N / 2, PITCH = N + 1, IMGB = N * PITCH * 8;     // bytes per {S,Q} image
-  constexpr int DB = N * 4, OB = NP * 4;                             // bytes per D / O image
-  constexpr int O_OFF = 2 * DB, DUMMY = 2 * DB + 2 * OB;             // dob layout: D[2][N], O[2][NP], dummy[N]
-  const int k = t / NP, l = t % NP;
-  {
-    float* Dg = reinterpret_cast<float*>(dob);
-    float* Og = reinterpret_cast<float*>(dob + O_OFF);
-    const f32x2* SQ = reinterpret_cast<const f32x2*>(sq);
-    for (int i = t; i < N; i += NP * NP) Dg[i] = SQ[i * PITCH + i][0];
-    for (int i = t; i < NP; i += NP * NP) Og[i] = SQ[i * PITCH + NP + i][0];          // set 0 pairs j with NP + j
-    __syncthreads();
-  }
-  const int row_pk = k * PITCH * 8, col_pl = l * 8;
-  const int a_pp = row_pk + col_pl;
-  int qk = NP + k, ql = NP + l;                                      // q index of set s: NP + ((j + s) & (NP - 1))
-  const int perm = ((t & (64 - NP)) | k) * 4;                        // ds_bpermute address of the lane with l == k
-  const int d_l = l * 4;                                             // D[.][p_l]
-  const int o_l = O_OFF + l * 4;                                     // O[.][l]
-  const int wd_pk = k == l ? k * 4 : DUMMY;                          // owner of D[.][p_k], D[.][q_k]
-  const bool own_d = k == l;
-  const int wo_k = l == ((k + 1) & (NP - 1)) ? O_OFF + k * 4 : DUMMY;  // owner of next set's O[.][k]
-  auto ldf = [&](const unsigned char* base, int off) { return *reinterpret_cast<const float*>(base + off); };
-  auto ld2 = [&](const unsigned char* base, int off) { return *reinterpret_cast<const f32x2*>(base + off); };
-  auto body = [&](auto CURC) {
-    constexpr int CUR = decltype(CURC)::value, NX = CUR ^ 1;
-    const unsigned char* C0 = sq + CUR * IMGB;
-    unsigned char* N0 = sq + NX * IMGB;
-    const int qlb = ql * 8, qkb = qk * (PITCH * 8);
-    const int a_pq = row_pk + qlb, a_qp = qkb + col_pl, a_qq = qkb + qlb;
-    const float lpp = ldf(dob + CUR * DB, d_l), lqq = ldf(dob + CUR * DB, ql * 4), lpq = ldf(dob + CUR * OB, o_l);
-    const f32x2 app = ld2(C0, a_pp), apq = ld2(C0, a_pq), aqp = ld2(C0, a_qp), aqq = ld2(C0, a_qq);
-    float cl, sl, offl, sigl;
-    jacobi_rotation(lpp, lqq, lpq, floor_m, cl, sl, offl, sigl);
-    my_off = fmaxf(my_off, offl);
-    my_sig = fmaxf(my_sig, sigl);
-    const float ck = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm, __builtin_bit_cast(int, cl)));
-    const float sk = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm, __builtin_bit_cast(int, sl)));
-    // columns (pair l) on S and Q, then rows (pair k) on S
-    const float ypp = cl * app[0] - sl * apq[0], ypq = sl * app[0] + cl * apq[0];
-    const float yqp = cl * aqp[0] - sl * aqq[0], yqq = sl * aqp[0] + cl * aqq[0];
-    f32x2 npp, npq, nqp, nqq;
-    npp[1] = cl * app[1] - sl * apq[1];  npq[1] = sl * app[1] + cl * apq[1];
-    nqp[1] = cl * aqp[1] - sl * aqq[1];  nqq[1] = sl * aqp[1] + cl * aqq[1];
-    npp[0] = ck * ypp - sk * yqp;  npq[0] = ck * ypq - sk * yqq;
-    nqp[0] = sk * ypp + ck * yqp;  nqq[0] = sk * ypq + ck * yqq;
-    *reinterpret_cast<f32x2*>(N0 + a_pp) = npp;  *reinterpret_cast<f32x2*>(N0 + a_pq) = npq;
-    *reinterpret_cast<f32x2*>(N0 + a_qp) = nqp;  *reinterpret_cast<f32x2*>(N0 + a_qq) = nqq;
-    *reinterpret_cast<float*>(dob + NX * DB + wd_pk) = npp[0];
-    *reinterpret_cast<float*>(dob + NX * DB + (own_d ? qk * 4 : DUMMY)) = nqq[0];
-    *reinterpret_cast<float*>(dob + NX * OB + wo_k) = npq[0];        // S[p_k][q_k] of the next set
-    qk = NP | ((qk + 1) & (NP - 1));
-    ql = NP | ((ql + 1) & (NP - 1));
-    __syncthreads();
-  };
-#pragma unroll 1
-  for (int s = 0; s < NP; s += 2) {
-    body(std::integral_constant<int, 0>{});
-    body(std::integral_constant<int, 1>{});
-  }
-  return 0;                                                          // NP is even: the result is back in image 0
-}
 
 // The cross sweep with ONE wave carrying the rotation parameters ("pivot wave"), the default since round 2.
 // In jacobi_cross_sets every thread derives rotation(l) itself (~35 instructions with three transcendentals on a
@@ -604,8 +537,15 @@ __device__ __forceinline__ int jacobi_cross_sets(unsigned char* sq, unsigned cha
 //   * within a set every element of the {S, Q} image is read and written by exactly one thread, so the image is
 //     updated in place (one image instead of two); with PITCH = N the 8-byte accesses of a diagonal are conflict-free.
 // Per set a bulk wave issues ~45 instructions instead of ~100, and the dependent chain of a set is the pivot wave's.
+// exp_mode: timing experiments of a -DWCT_TUNING build (WCT_JACOBI_DBG: results INVALID); constant 0 in the product, so
+// none of their predicates exists in the shipped kernels
 template <int N>
-__device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned char* csb, int t, float floor_m, float& my_off, float& my_sig, int exp_mode = 0) {
+__device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned char* csb, int t, float floor_m, float& my_off, float& my_sig, int exp_mode_in = 0) {
+#ifdef WCT_TUNING
+  const int exp_mode = exp_mode_in;
+#else
+  constexpr int exp_mode = 0;
+#endif
   constexpr int NP = N / 2, ROWB = N * 8;                            // bytes per image row
   constexpr int CSB = NP * 8, DUMMY = 2 * CSB;                       // csb layout: CS[2][NP] float2 (c, s), dummy float2
   const int k = t & (NP - 1), d = t / NP;
@@ -683,203 +623,10 @@ __device__ __forceinline__ void jacobi_cross_sets_pw(unsigned char* sq, unsigned
   }
 }
 
-// measured (tools/probe/jacobi_probe.hip): more blocks per thread is SLOWER (N = 64: 1761 / 1930 / 2412 / 3643 cycles per
-// set for KB = 1 / 2 / 4 / 8; with two blocks resident per CU 2910 vs 3010) -- fewer waves hide less LDS latency -- so KB = 1
-template <int M2> struct JacobiCfg { static constexpr int KB = 1; static constexpr int NT = (M2 / 2) * (M2 / 2) / KB; };
-
-// One outer step: pair problem of blocks (bi, bj) -> rotation matrix Q (M2 x M2) in Qbuf.
-// PW: the cross steps run jacobi_cross_sets_pw on an in-place image of pitch M2 (LDS: jacobi_diag_lds<M2>(step, pw)).
-// A non-finite element anywhere in the pair problem makes the block report an infinite off-diagonal measure, which
-// jacobi_check_kernel turns into done = 2 ("failed: non-finite input") instead of a silent "converged".
-template <int M2, bool PW>
-__global__ __launch_bounds__(JacobiCfg<M2>::NT) void jacobi_diag_kernel(float* A, float* Qbuf, JacobiState* st, int C, int step) {
-  constexpr int B = M2 / 2, NT = JacobiCfg<M2>::NT, KB = JacobiCfg<M2>::KB;
-  const int m = blockIdx.y, g = blockIdx.x;
-  if (st[m].done) return;
-  extern __shared__ __attribute__((aligned(16))) float jsm[];
-  f32x2* SQ = reinterpret_cast<f32x2*>(jsm);
-  const int tid = threadIdx.x;
-  const int nblk = C / B, npair = nblk / 2;
-  int bi, bj;
-  block_pair(g, step, nblk, bi, bj);
-  float* Am = A + (size_t)m * C * C;
-  float* Qo = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
-  float my_off = 0.f, my_sig = 0.f, my_dm = 0.f;
-  const float floor_m = st[m].floor;
-  bool finite = true;
-  if (PW && step >= 0) {
-    for (int e = tid; e < M2 * M2; e += NT) {
-      const int r = e / M2, c = e % M2;
-      f32x2 v;
-      v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
-      v[1] = r == c ? 1.f : 0.f;
-      finite &= fabsf(v[0]) <= 3.0e38f;
-      if (r == c) my_dm = fmaxf(my_dm, fabsf(v[0]));
-      SQ[e] = v;
-    }
-    __syncthreads();
-    jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig);
-    for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[e][1];
-  } else {
-    constexpr int PITCH = M2 + 1;                       // [2][M2][PITCH] ping-pong images
-    for (int e = tid; e < M2 * M2; e += NT) {
-      const int r = e / M2, c = e % M2;
-      f32x2 v;
-      v[0] = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
-      v[1] = r == c ? 1.f : 0.f;
-      finite &= fabsf(v[0]) <= 3.0e38f;
-      if (r == c) my_dm = fmaxf(my_dm, fabsf(v[0]));
-      SQ[r * PITCH + c] = v;
-    }
-    __syncthreads();
-    float* DO = jsm + 4 * M2 * PITCH;                   // after the two float2 images
-    const int cur = step < 0 ? jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, floor_m, my_off, my_sig)
-                             : jacobi_cross_sets<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(DO), tid, floor_m, my_off, my_sig);
-    for (int e = tid; e < M2 * M2; e += NT) Qo[e] = SQ[cur * M2 * PITCH + (e / M2) * PITCH + (e % M2)][1];
-  }
-  if (!finite) my_off = __builtin_inff();
-  for (int o = 32; o > 0; o >>= 1) {
-    my_off = fmaxf(my_off, __shfl_xor(my_off, o, 64));
-    my_sig = fmaxf(my_sig, __shfl_xor(my_sig, o, 64));
-    my_dm = fmaxf(my_dm, __shfl_xor(my_dm, o, 64));
-  }
-  if ((tid & 63) == 0) {
-    if (my_off > 0.f) atomicMax(&st[m].offmax, __float_as_uint(my_off));
-    if (my_sig > 0.f) atomicMax(&st[m].offsig, __float_as_uint(my_sig));
-    // largest diagonal of the pair problem as loaded -> next sweep's floor (taken from the values already in registers:
-    // re-reading the diagonal from global memory put one more dependent memory round trip at the end of every block)
-    if (my_dm > 0.f && my_dm < 3.0e38f) atomicMax(&st[m].dmax, __float_as_uint(my_dm));
-  }
-}
-
 template <int M2>
 static size_t jacobi_diag_lds(int step, bool pw) {
   if (pw && step >= 0) return (size_t)M2 * M2 * sizeof(f32x2) + (size_t)(M2 + 2) * sizeof(f32x2);   // image, CS[2][M2/2], dummy
   return (size_t)2 * M2 * (M2 + 1) * sizeof(f32x2) + 4 * M2 * sizeof(float);                         // images, D[2][M2], O[2][M2/2], dummy[M2]
-}
-
-// acc (32x32 MFMA C/D layout) -> the 16 B operands of the next 32x32x2 MFMA chain, in
-// registers: rows kk, kk+1 sit in one half-wave and rows kk+4, kk+5 in the other, one
-// v_permlane32_swap per register pair puts row kk / kk+1 (and kk+4 / kk+5) into the
-// lower / upper half.  b[kk/2] is the operand of k-step kk.
-__device__ __forceinline__ void acc_to_b_operands(const f32x16& acc, float (&b)[16]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int r = 4 * q + 2 * p;
-      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[r]), __float_as_uint(acc[r + 1]), false, false);
-      b[(8 * q + 2 * p) / 2] = __uint_as_float(sw[0]);
-      b[(8 * q + 2 * p + 4) / 2] = __uint_as_float(sw[1]);
-    }
-}
-
-// (Round 2 experiment, removed: V -- 56 % of this kernel's HBM traffic, which the solver itself never reads -- brought
-// up to date once per SWEEP instead, from the sweep's stored Q tiles, with a 32- or 64-row panel of V resident in LDS
-// (rotations act on columns: row panels are independent).  Bit-compatible, the tile update dropped 39 -> 23 us per
-// launch, but the V flops then run in a kernel of their own that is bound by the fp32-MFMA rate and by the serial
-// chain of C^2/2B^2 dependent tile products per panel: 295-444 us per launch of 16 matrices; Jacobi 29.9 vs 23.6 ms
-// per 32-pair step, 12.8 vs 9.2 ms at batch 1.  In the tile update the same flops hide under the memory traffic.)
-// One M2 x M2 tile per block: 64 threads (one wave) for M2 = 32, 256 threads (2x2 waves of
-// 32x32 quadrants) for M2 = 64.  grid (2*npair*npair, nmat): first the A tiles (g, h), then
-// the V tiles (row block g, column pair h).
-template <int M2>
-__global__ __launch_bounds__(M2 == 32 ? 64 : 256) void jacobi_update_kernel(float* A, float* V, const float* Qbuf, const JacobiState* st, int C, int step) {
-  constexpr int B = M2 / 2, PITCH = M2 + 1;
-  const int m = blockIdx.y;
-  if (st[m].done) return;
-  __shared__ float Xs[M2 * PITCH];
-  __shared__ float Qh[M2 * PITCH];
-  __shared__ float Qg[M2 * PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nthr = M2 == 32 ? 64 : 256;
-  const int nblk = C / B, npair = nblk / 2;
-  // A is symmetric: for M2 = 64 only the tiles g <= h are computed, and Y^T is written to (h, g)
-  constexpr bool SYM = M2 == 64;
-  const int n_a_tiles = SYM ? npair * (npair + 1) / 2 : npair * npair;
-  int t = blockIdx.x;
-  const bool is_v = t >= n_a_tiles;
-  if (is_v) t -= n_a_tiles;
-  int g, h;                                     // for V tiles g is the M2-row block index
-  if (SYM && !is_v) { g = 0; while (t >= npair - g) { t -= npair - g; ++g; } h = g + t; }
-  else { g = t / npair; h = t % npair; }
-  int hi, hj, gi = 0, gj = 0;
-  block_pair(h, step, nblk, hi, hj);
-  if (!is_v) block_pair(g, step, nblk, gi, gj);
-  float* X = (is_v ? V : A) + (size_t)m * C * C;
-  const float* Qhp = Qbuf + ((size_t)m * npair + h) * (M2 * M2);
-  const float* Qgp = Qbuf + ((size_t)m * npair + g) * (M2 * M2);
-  // 16-byte global loads, all issued before the first LDS write (the column index runs inside one
-  // 16-float / 32-float block, so a float4 never straddles the two blocks of a pair)
-  constexpr int NV = M2 * M2 / 4 / (M2 == 32 ? 64 : 256);       // float4 per thread per matrix
-  f32x4 xv[NV], hv[NV], gv[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = (tid + i * nthr) * 4;
-    const int r = e / M2, c = e % M2;
-    const int gr = is_v ? g * M2 + r : pair_index<B>(r, gi, gj);
-    xv[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * C + pair_index<B>(c, hi, hj));
-    hv[i] = *reinterpret_cast<const f32x4*>(Qhp + e);
-    if (!is_v) gv[i] = *reinterpret_cast<const f32x4*>(Qgp + e);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = (tid + i * nthr) * 4;
-    const int r = e / M2, c = e % M2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      Xs[r * PITCH + c + j] = xv[i][j];
-      Qh[r * PITCH + c + j] = hv[i][j];
-      if (!is_v) Qg[r * PITCH + c + j] = gv[i][j];
-    }
-  }
-  __syncthreads();
-  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;     // quadrant origin (0,0 for M2 = 32)
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int li = lane & 31, lk = lane >> 5;
-#pragma unroll 8
-  for (int kk = 0; kk < M2; kk += 2)      // T = X . Qh
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[(wi + li) * PITCH + kk + lk], Qh[(kk + lk) * PITCH + wj + li], acc, 0, 0, 0);
-  if (!is_v) {
-    if (M2 == 32) {
-      float bop[16];
-      acc_to_b_operands(acc, bop);          // T stays in registers
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int kk = 0; kk < 32; kk += 2)  // Y = Qg^T . T
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qg[(kk + lk) * PITCH + li], bop[kk / 2], acc, 0, 0, 0);
-    } else {
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) Xs[(wi + (r & 3) + 8 * (r >> 2) + 4 * lk) * PITCH + wj + li] = acc[r];
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-      for (int kk = 0; kk < M2; kk += 2)  // Y = Qg^T . T
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qg[(kk + lk) * PITCH + wi + li], Xs[(kk + lk) * PITCH + wj + li], acc, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = wi + (r & 3) + 8 * (r >> 2) + 4 * lk;
-    const int gr = is_v ? g * M2 + row : pair_index<B>(row, gi, gj);
-    X[(size_t)gr * C + pair_index<B>(wj + li, hi, hj)] = acc[r];
-  }
-  if (SYM && !is_v && g != h) {
-    // mirror tile: transpose through LDS so the global stores stay row-contiguous
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Xs[(wi + (r & 3) + 8 * (r >> 2) + 4 * lk) * PITCH + wj + li] = acc[r];
-    __syncthreads();
-    for (int e = tid; e < M2 * M2; e += nthr) {
-      const int c = e / M2, r = e % M2;           // element Y[r][c] -> A[idx_h(c)][idx_g(r)]
-      X[(size_t)pair_index<B>(c, hi, hj) * C + pair_index<B>(r, gi, gj)] = Xs[r * PITCH + c];
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -931,7 +678,7 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
   float* Qo = p.Qw + ((size_t)m * npair + g) * (M2 * M2);
   float* So = p.Sw + ((size_t)m * npair + g) * (M2 * M2);
   if (p.first) {
-    if (p.st[m].done || (p.dbg & 2)) return;
+    if (p.st[m].done || (JDBG(p) & 2)) return;
     floor_m = p.st[m].floor;
     JTS(1);
     const float* Am = p.Pr + (size_t)m * C * C;
@@ -989,7 +736,7 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
       qv = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + (one ? g1 : g2)) * (M2 * M2) + (size_t)f * 4);
       Qdst = (one ? Q1s : Q2s) + qr * (B + 1) + qc;
     }
-    if (p.st[m].done || (p.dbg & 2)) return;        // (block-uniform)
+    if (p.st[m].done || (JDBG(p) & 2)) return;        // (block-uniform)
     floor_m = p.st[m].floor;
     JTS(1);
     f32x4 crit = {0.f, 0.f, 0.f, 0.f};
@@ -1043,7 +790,7 @@ __device__ __forceinline__ void jacobi_fused_d(const JacobiFusedArgs& p, int m, 
   }
   JTS(4);
   if (p.step_d >= 0) {
-    if (!(p.dbg & 4)) jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig, p.dbg);
+    if (!(JDBG(p) & 4)) jacobi_cross_sets_pw<M2>(reinterpret_cast<unsigned char*>(SQ), reinterpret_cast<unsigned char*>(jsm + 2 * M2 * M2), tid, floor_m, my_off, my_sig, JDBG(p));
     JTS(5);
     for (int e = tid; e < M2 * M2; e += NT) So[e] = SQ[e][0];
     int qr, qc;
@@ -1209,7 +956,7 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_
   } else {
     b -= n_d;
     const int task = b / p.nmat, m = b % p.nmat;
-    if (p.st[m].done || (p.dbg & 1)) return;
+    if (p.st[m].done || (JDBG(p) & 1)) return;
     jacobi_fused_u<M2>(p, m, task, jsm);
   }
 }
@@ -1283,7 +1030,7 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
   constexpr int NLD = FR / 4 / (W * 64) > 0 ? FR / 4 / (W * 64) : 1;        // float4 per thread and tile
   __shared__ __attribute__((aligned(16))) float qs[2][FR];
   const int m = blockIdx.y;
-  if (p.st[m].seg_stop <= p.seg || p.dbg) return;   // no rotations of this segment belong to the matrix (done before it began)
+  if (p.st[m].seg_stop <= p.seg || JDBG(p)) return;   // no rotations of this segment belong to the matrix (done before it began)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int row0 = (blockIdx.x * W + wave) * 16;
@@ -1452,7 +1199,7 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
 // mixed_w: weight of the kept-x-dropped couplings in the STRICT measure.  The second-order completion covers the block of
 // kept eigenvalues only, so when the stop threshold is raised for it (4e-2 instead of 1.5e-2) the couplings across the
 // cut-off keep their old bound: their squared measure is weighted by (4 / 1.5)^2.
-__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const JacobiState* st, float* partial, int C, float mixed_w = 1.f) {
+__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, JacobiState* st, float* partial, int C, float mixed_w = 1.f) {
   __shared__ float red[4][4];
   __shared__ float dg[1024];                           // |a_ii| of the whole matrix (C <= 1024)
   __shared__ float idg[1024];                          // 1 / |a_ii| (0 for a zero diagonal: such pairs take the `mixed` form)
@@ -1472,7 +1219,11 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
   }
   // an eigenvalue within half a decade of the cut-off: its kept / dropped side can still change, and a pair of the kept
   // block may really be a pair across the cut-off -- such a matrix keeps the old bound on ALL its couplings
-  const float kk_w = __syncthreads_or(near) ? mixed_w : 1.f;
+  const int near_any = __syncthreads_or(near);
+  const float kk_w = near_any ? mixed_w : 1.f;
+  // remembered for jacobi_finalize_kernel: such a matrix has only the first-order completion to pay for a late
+  // acceptance; every chunk computes the same flag from the same diagonal, chunk 0 records it
+  if (ch == 0 && tid == 0) st[m].pad2 = near_any ? 1 : 0;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   for (int q = tid; q < C; q += 256) {                 // at most four columns per thread; rows stream coalesced
     const float dq = dg[q], iq = idg[q];
@@ -1572,7 +1323,10 @@ __global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, i
   // out of sweeps: good enough after all if the last sweep's significant pairs were below tol_max, or if the lenient
   // residual is within 4x of the target (second-order error 16x the target's: still inside the 1e-3 budget)
   // (second-order completion: error ~ r^3, and its stop threshold is already 4e-2 -- twice that is the most the 1e-3 budget takes)
-  const float tol_l = tol_fn > 0.f ? (tol_fn > 2e-2f ? 2.f : 4.f) * tol_fn : tol_max;
+  // -- except for a matrix with an eigenvalue near the cut-off (pad2, jacobi_resid_kernel): it keeps the first-order completion
+  // and with it the first-order bound 4 x 1.5e-2
+  const bool near_cut = m < nmat && st[m].pad2 != 0;
+  const float tol_l = tol_fn > 0.f ? (tol_fn > 2e-2f ? (near_cut ? 4.f * 1.5e-2f : 2.f * tol_fn) : 4.f * tol_fn) : tol_max;
   if (d == 0 && (__uint_as_float(st[m].last_sig) < tol_max || (st[m].r2l >= 0.f && st[m].r2l < tol_l * tol_l))) d = 1;
   if (m < nmat && sweeps_out) sweeps_out[m] = d == 1 ? st[m].sweeps : (d == 2 ? -1000 - st[m].sweeps : -st[m].sweeps);
   const int n_open = __builtin_popcountll(__ballot(d == 0)), n_nan = __builtin_popcountll(__ballot(d == 2));
@@ -1647,96 +1401,8 @@ static JacobiHost* jacobi_host() {
   return &h;
 }
 
-// cross-step kernel: 1 = pivot wave on the in-place {S, Q} image (jacobi_cross_sets_pw, default), 0 = the round-1
-// kernel -- WCT_JACOBI_PW, an A-B switch.  (A third variant was built and measured in round 2 and removed: only the
-// blocks on one side of the diagonal rotated, with mirrored stores, and Q carried by one extra wave, a row per lane in
-// registers -- 10 waves and 17 KB per pair problem, bit-compatible results; but that wave needs 4 NP dependent-free
-// FMAs + NP/2 LDS loads per set on ONE SIMD, ~700 cycles, longer than the whole set of the kernel below: Jacobi
-// 26.6 vs 23.8 ms per 32-pair step, 10.8 vs 9.5 ms at batch 1.)
-static int jacobi_pw_mode() {
-  static const int pw = getenv("WCT_JACOBI_PW") ? atoi(getenv("WCT_JACOBI_PW")) : 1;
-  return pw;
-}
-
-// steps [step_begin, step_end) of one sweep: step -1 rotates the pairs inside each block, steps 0.. the cross pairs
-// of every block pair -- each pair of indices exactly once per sweep.  Launches of the groups are interleaved.
-template <int M2>
-static void jacobi_enqueue_steps(const JacobiGroup* grp, int ngrp, int C, int step_begin, int step_end) {
-  constexpr int B = M2 / 2;
-  const int nblk = C / B, npair = nblk / 2;
-  const int mode = jacobi_pw_mode();
-  const bool pw = mode != 0;
-  for (int step = step_begin; step < step_end; ++step)
-    for (int g = 0; g < ngrp; ++g) {
-      const JacobiGroup& G = grp[g];
-      const size_t lds = jacobi_diag_lds<M2>(step, pw);
-      if (pw) hipLaunchKernelGGL((jacobi_diag_kernel<M2, true>), dim3(npair, G.nmat), dim3(JacobiCfg<M2>::NT), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
-      else hipLaunchKernelGGL((jacobi_diag_kernel<M2, false>), dim3(npair, G.nmat), dim3(JacobiCfg<M2>::NT), lds, G.stream, G.A, G.Qbuf, G.st, C, step);
-      hipLaunchKernelGGL((jacobi_update_kernel<M2>), dim3((M2 == 64 ? npair * (npair + 1) / 2 : npair * npair) + npair * npair, G.nmat),
-                         dim3(M2 == 32 ? 64 : 256), 0, G.stream, G.A, G.V, G.Qbuf, G.st, C, step);
-    }
-}
-
-// Sweeps until every matrix of every group is done or the sweep budget is spent.  The `done` flag turns the launches
-// of a finished matrix into no-ops on the device; to stop LAUNCHING, the host reads the flags back -- asynchronously:
-// the copy of sweep k's flags is waited for only after the first half of sweep k+1 has been enqueued, so the GPU
-// never idles behind the host (round 1 synchronised the streams after every sweep from the 4th on).  When the
-// flags say "all done" the half sweep already in flight is a run of no-op launches (~2 us apiece).
-template <int M2>
-static int jacobi_run_groups(JacobiGroup* grp, int ngrp, int C) {
-  constexpr int B = M2 / 2;
-  const int nblk = C / B;
-  const int half = -1 + nblk / 2;                 // steps [-1, half) | [half, nblk - 1)
-  const int max_sweeps = jacobi_max_sweeps();
-  static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
-  // first sweep with a residual test in its middle as well (-1: never); before the fourth sweep no matrix of this size class
-  // is anywhere near the threshold, and below 8 blocks a half sweep is too short to be worth a measurement
-  static const int mid_env = getenv("WCT_JACOBI_MID") ? atoi(getenv("WCT_JACOBI_MID")) : 3;
-  const int mid_from = nblk >= 8 ? mid_env : -1;
-  JacobiHost* host = jacobi_host();
-  for (int g = 0; g < ngrp; ++g)
-    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].V, grp[g].st, C,
-                       grp[g].mat0, grp[g].shared_style);
-  bool pending = false;                           // a copy of the previous sweep's flags is in flight
-  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    jacobi_enqueue_steps<M2>(grp, ngrp, C, -1, half);
-    if (pending) {
-      bool all = true;
-      for (int g = 0; g < ngrp; ++g) {
-        HIP_TRY(hipEventSynchronize(host->ev[g]));
-        for (int m = 0; m < grp[g].nmat; ++m) all = all && host->flags[g * 64 + m].done != 0;
-      }
-      pending = false;
-      if (all) break;
-    }
-    if (mid_from >= 0 && sweep >= mid_from)
-      for (int g = 0; g < ngrp; ++g)
-        if (grp[g].tol_fn > 0.f) {
-          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
-          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, 0);
-        }
-    jacobi_enqueue_steps<M2>(grp, ngrp, C, half, nblk - 1);
-    for (int g = 0; g < ngrp; ++g) {
-      hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].A, grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, 0, 0, max_sweeps - 3);
-    }
-    if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
-      for (int g = 0; g < ngrp; ++g) {
-        HIP_TRY(hipMemcpyAsync(host->flags + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, grp[g].stream));
-        HIP_TRY(hipEventRecord(host->ev[g], grp[g].stream));
-      }
-      pending = true;
-    }
-  }
-  for (int g = 0; g < ngrp; ++g)
-    if (grp[g].sweeps_out || grp[g].fail || grp[g].stats)
-      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].sweeps_out, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].fail, getenv("WCT_JACOBI_DEBUG") != nullptr, grp[g].stats);
-  HIP_TRY(hipGetLastError());
-  return WCT_OK;
-}
-
 static int jacobi_r4_mode() {
-  static const int on = getenv("WCT_JACOBI_R4") ? atoi(getenv("WCT_JACOBI_R4")) : 1;
+  static const int on = tune_int("WCT_JACOBI_R4", 1);
   return on;
 }
 
@@ -1755,7 +1421,7 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
   a.Sr = G.Sb[G.par]; a.Sw = G.Sb[G.par ^ 1];
   a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_d = step_d; a.step_u = step_u;
   a.has_d = has_d; a.has_u = has_u; a.first = first; a.with_v = !G.vstrip;
-  static const int dbg = getenv("WCT_JACOBI_DBG") ? atoi(getenv("WCT_JACOBI_DBG")) : 0;
+  static const int dbg = tune_int("WCT_JACOBI_DBG", 0);
   a.dbg = dbg;
   const unsigned grid = (has_d ? G.nmat * npair : 0) + (has_u ? G.nmat * ntask : 0);
   // round 4 (M2 = 64): pair problems resident in registers, 256 threads per pair problem and per update task (namespace
@@ -1830,7 +1496,7 @@ static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_
   const int nblk = C / (M2 / 2);
   VStripArgs a;
   a.V = G.V; a.Qlog = G.Qlog16[G.lg]; a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_begin = step_begin; a.step_end = step_end; a.seg = G.segs;
-  static const int dbg = getenv("WCT_JACOBI_DBG") ? atoi(getenv("WCT_JACOBI_DBG")) : 0;
+  static const int dbg = tune_int("WCT_JACOBI_DBG", 0);
   a.dbg = dbg & 128;
 #define VSTRIP_CASE(m2, nb, w) \
   if (M2 == m2 && nblk == nb) hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), dim3(C / 16 / w, G.nmat), dim3(w * 64), 0, s, a);
@@ -1880,11 +1546,11 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
   const int nblk = C / B;
   const int half = -1 + nblk / 2;                 // steps [-1, half) | [half, nblk - 1)
   const int max_sweeps = jacobi_max_sweeps();
-  static const float conv_tol = getenv("WCT_JACOBI_CONV_TOL") ? (float)atof(getenv("WCT_JACOBI_CONV_TOL")) : JACOBI_CONV_TOL;
-  static const int mid_env = getenv("WCT_JACOBI_MID") ? atoi(getenv("WCT_JACOBI_MID")) : 3;
+  static const float conv_tol = tune_float("WCT_JACOBI_CONV_TOL", JACOBI_CONV_TOL);
+  static const int mid_env = tune_int("WCT_JACOBI_MID", 3);
   // V in registers, per segment (jacobi_vstrip_kernel): 0 never, 1 from WCT_JACOBI_VSTRIP_MIN matrices per group on, 2 always
-  static const int vs_env = getenv("WCT_JACOBI_VSTRIP") ? atoi(getenv("WCT_JACOBI_VSTRIP")) : 1;
-  static const int vs_min = getenv("WCT_JACOBI_VSTRIP_MIN") ? atoi(getenv("WCT_JACOBI_VSTRIP_MIN")) : 24;
+  static const int vs_env = tune_int("WCT_JACOBI_VSTRIP", 1);
+  static const int vs_min = tune_int("WCT_JACOBI_VSTRIP_MIN", 24);
   const int mid_from = nblk >= 8 ? mid_env : -1;
   JacobiHost* host = jacobi_host();
   for (int g = 0; g < ngrp; ++g) {
@@ -1944,7 +1610,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
       if (G.vstrip && G.v_busy[l]) { HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_v[l], 0)); G.v_busy[l] = false; }
     hipLaunchKernelGGL(jacobi_gather_kernel, dim3(32, G.nmat), dim3(256), 0, G.stream, G.A, G.P[1], G.st, C, G.cur);
     if (G.sweeps_out || G.fail || G.stats)
-      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, G.stream, G.st, G.sweeps_out, G.nmat, conv_tol, G.tol_fn, G.fail, getenv("WCT_JACOBI_DEBUG") != nullptr, G.stats);
+      hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, G.stream, G.st, G.sweeps_out, G.nmat, conv_tol, G.tol_fn, G.fail, tune_set("WCT_JACOBI_DEBUG"), G.stats);
   }
   HIP_TRY(hipGetLastError());
   return WCT_OK;
@@ -1972,14 +1638,13 @@ static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat
 
 static int jacobi_dispatch(JacobiGroup* grp, int ngrp, int C) {
   // block pairs of 64 indices (32-column blocks) by default; WCT_JACOBI_M2=32 selects 16-column blocks
-  static const int force32 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 32 : 0;
-  static const int force64 = getenv("WCT_JACOBI_M2") ? atoi(getenv("WCT_JACOBI_M2")) == 64 : 0;
+  static const int force32 = tune_int("WCT_JACOBI_M2", 0) == 32;
+  static const int force64 = tune_int("WCT_JACOBI_M2", 0) == 64;
   // measured (16 matrices): 64-wide pairs win from C = 256 up (half the tile traffic), 32-wide below
-  // look-ahead launches (default) or the round-2 two-launch steps (WCT_JACOBI_FUSED=0, an A-B switch)
-  static const int fused = getenv("WCT_JACOBI_FUSED") ? atoi(getenv("WCT_JACOBI_FUSED")) : 1;
+  // (the round-2 two-launch steps -- separate pair-problem and tile-update kernels -- were deleted in round 4: the
+  //  look-ahead launches have been the only path since round 3)
   const bool m64 = !force32 && C % 64 == 0 && (C >= 256 || force64);
-  if (fused && jacobi_pw_mode()) return m64 ? jacobi_run_groups_fused<64>(grp, ngrp, C) : jacobi_run_groups_fused<32>(grp, ngrp, C);
-  return m64 ? jacobi_run_groups<64>(grp, ngrp, C) : jacobi_run_groups<32>(grp, ngrp, C);
+  return m64 ? jacobi_run_groups_fused<64>(grp, ngrp, C) : jacobi_run_groups_fused<32>(grp, ngrp, C);
 }
 
 // statistics slot of stream group g for matrices of order C inside the caller's status words: after the 8 failure
@@ -2102,7 +1767,7 @@ __global__ void spectral_add2_kernel(const float* A, float* G, const float* X1, 
 
 // 0: spectral functions of the diagonal only, 1: + first-order completion, 2 (default): + second-order completion
 static int eig_correct_enabled() {
-  static const int on = getenv("WCT_EIG_CORRECT") ? atoi(getenv("WCT_EIG_CORRECT")) : 2;
+  static const int on = tune_int("WCT_EIG_CORRECT", 2);
   return on;
 }
 // residual at which the WCT path stops sweeping.  Calibrated on the level features of a 512x512 frame
@@ -2113,9 +1778,8 @@ constexpr float JACOBI_TOL_FN = 1.5e-2f;
 constexpr float JACOBI_TOL_FN2 = 4e-2f;            // with the second-order completion (profiles/r03_eig_calibration.txt: the transform error
                                                    // at 4e-2 with it, 3.1e-5 .. 1.3e-4, is what 1.5e-2 gave without it, one sweep later)
 static float jacobi_tol_fn() {
-  static const float t = getenv("WCT_JACOBI_TOL_FN") ? (float)atof(getenv("WCT_JACOBI_TOL_FN"))
-                                                     : (eig_correct_enabled() >= 2 ? JACOBI_TOL_FN2 : (eig_correct_enabled() ? JACOBI_TOL_FN : 0.f));
-  return t;          // an explicit WCT_JACOBI_TOL_FN also applies without the completion (calibration runs)
+  static const float t = tune_float("WCT_JACOBI_TOL_FN", eig_correct_enabled() >= 2 ? JACOBI_TOL_FN2 : (eig_correct_enabled() ? JACOBI_TOL_FN : 0.f));
+  return t;          // (tuning builds: an explicit WCT_JACOBI_TOL_FN also applies without the completion -- calibration runs)
 }
 
 // out[b] = V[b] G[b] V[b]^T for nbatch matrices (strides in elements); X: scratch of the same shape as G
@@ -2491,10 +2155,10 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       // problems hide under the other groups' tile updates; few: every extra stream only adds launch traffic
       // round 3: with the look-ahead launches a group's pair problems already run beside its own tile update, and more
       // groups only split the chip (Jacobi ms per step, 1 / 2 / 4 groups: batch 32: 20.6 / 21.0 / 22.5, batch 8: 9.3 / 11.9 / 10.0)
-      static const int fused_on = getenv("WCT_JACOBI_FUSED") ? atoi(getenv("WCT_JACOBI_FUSED")) : 1;
+      static const int fused_on = tune_int("WCT_JACOBI_FUSED", 1);
       int ngrp = fused_on ? 1 : (P >= 12 ? 4 : (P >= 6 ? 2 : 1));
       if (ngrp > nside + 1) ngrp = nside + 1;
-      static const int force_ngrp = getenv("WCT_EIG_NGRP") ? atoi(getenv("WCT_EIG_NGRP")) : 0;   // tuning switch
+      static const int force_ngrp = tune_int("WCT_EIG_NGRP", 0);   // tuning switch
       if (force_ngrp >= 1 && force_ngrp <= 4 && force_ngrp <= nside + 1) ngrp = force_ngrp;
       JacobiGroup grp[4];
       HIP_TRY(hipEventRecord(ev_fork, s));
