@@ -137,6 +137,7 @@ void run_block(int nt, int bx, F fn) {
 }
 }  // namespace emul
 
+#define R4_OPAQUE(x) ((void)0)
 #define threadIdx emul::tidx
 #define blockIdx emul::bidx
 #define __syncthreads() emul::syncthreads()

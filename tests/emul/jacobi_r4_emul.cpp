@@ -13,7 +13,7 @@ namespace emul { thread_local Idx tidx; thread_local Idx bidx; thread_local Bloc
 #include <stdlib.h>
 #include "../../wct_tf_amd/csrc/jacobi_dev.h"
 #ifndef EMUL_VAR
-#define EMUL_VAR 1              // 1: strips (the shipped variant), 0: 2 x 2 patches
+#define EMUL_VAR 0              // strip layout: 0 = 8 strips on 4 waves (the shipped one), 1 = 16 strips on 8 waves
 #endif
 
 static int failures = 0;
@@ -112,7 +112,7 @@ struct Solver {
   void run_d(const JacobiFusedArgs& a) {
     for (int g = 0; g < npair; ++g) {
       std::fill(lds.begin(), lds.end(), __builtin_nanf(""));          // LDS is not initialised on the device either
-      emul::run_block(r4::NT, g, [&](int) { r4::fused_d<M2, true, EMUL_VAR>(a, 0, g, lds.data()); });
+      emul::run_block(r4::Lay<EMUL_VAR>::NTD, g, [&](int) { r4::fused_d<M2, EMUL_VAR>(a, 0, g, lds.data()); });
     }
   }
   void run_u(const JacobiFusedArgs& a, bool with_v) {

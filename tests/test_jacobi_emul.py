@@ -14,7 +14,7 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason='ROCm clang++ not found')
-@pytest.mark.parametrize('variant', [1, 0], ids=['strips', 'patches'])
+@pytest.mark.parametrize('variant', [0, 1], ids=['8-strips-4-waves', '16-strips-8-waves'])
 def test_r4_pair_problem_source_emulated_on_the_cpu(tmp_path, variant):
     exe = str(tmp_path / 'jacobi_r4_emul')
     src = os.path.join(ROOT, 'tests', 'emul', 'jacobi_r4_emul.cpp')

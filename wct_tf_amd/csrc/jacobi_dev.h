@@ -6,6 +6,9 @@
 #pragma once
 #include <type_traits>
 #include <utility>
+#ifndef R4_OPAQUE
+#define R4_OPAQUE(x) asm volatile("" : "+v"(x))     // the optimiser may not look through the value (no instruction emitted)
+#endif
 #ifndef JTS
 #define JTS(slot) do {} while (0)       // phase stamps of the -DJACOBI_TS build (wct.hip defines the real one)
 #endif
@@ -287,142 +290,6 @@ __device__ __forceinline__ void split_f16x8(const float (&x)[8], half8& hi, half
 // =====================================================================================================================
 namespace r4 {
 constexpr int NT = 256;                    // threads per pair problem / per update task
-constexpr int SLOT_B = 48;                 // bytes a lane publishes per set: 11 floats + pad
-constexpr int SLOTS_B = NT * SLOT_B;       // one exchange buffer
-constexpr int CS_OFF = 2 * SLOTS_B;        // CS[2][32] float2 (c, s) behind the two exchange buffers
-constexpr int CS_B = 32 * 8;
-constexpr int DUMMY_OFF = CS_OFF + 2 * CS_B;   // 16 bytes that absorb the stores of lanes owning no pair
-constexpr int XCHG_B = DUMMY_OFF + 16;
-
-struct Patch {                             // P = 2: [i][j] = cell (k = 2 I + i, d = 2 Dd + j)
-  float pp[2][2], pq[2][2], qp[2][2], qq[2][2];
-  float Qpp[2][2], Qpq[2][2], Qqp[2][2], Qqq[2][2];
-};
-
-// The 32 cross sets on a patch-resident pair problem.  xb: exchange area (XCHG_B bytes of LDS), simg: the S image
-// [64][64] (read for the initial pivots only).  All 256 threads of the block call this together.
-template <bool PWAVE, bool DPP = true>
-__device__ __forceinline__ void cross_sets(Patch& R, unsigned char* xb, const float* simg, int t, float floor_m, float& my_off, float& my_sig) {
-  const int I = t & 15, Dd = t >> 4;
-  const bool piv = PWAVE && Dd == 0;                                   // lanes 0..15 of wave 0 own pairs 2 I, 2 I + 1
-  const int a_own = t * SLOT_B;
-  const int a_right = (((Dd + 1) & 15) * 16 + I) * SLOT_B;             // lane (I, Dd + 1)
-  const int a_down = (Dd * 16 + ((I + 1) & 15)) * SLOT_B;              // lane (I + 1, Dd)
-  const int a_left = (((Dd - 1) & 15) * 16 + I) * SLOT_B;              // lane (I, Dd - 1)
-  const int a_upleft = (((Dd - 1) & 15) * 16 + ((I + 1) & 15)) * SLOT_B;   // lane (I + 1, Dd - 1)
-  const int l0 = (2 * I + 2 * Dd + 1) & 31, l1 = (l0 + 1) & 31;        // l of cell (i, j) = l0 + i + j; l1 is even
-  const int a_k = CS_OFF + I * 16, a_l0 = CS_OFF + l0 * 8, a_l1 = CS_OFF + l1 * 8;
-  const int a_csw = piv ? CS_OFF + I * 16 : DUMMY_OFF;
-  float ppk[2] = {0.f, 0.f}, qqk[2] = {0.f, 0.f}, pqk[2] = {0.f, 0.f};  // the pivot blocks of pairs 2 I + i (pivot lanes)
-  if (PWAVE) {
-    __builtin_amdgcn_s_setprio(2);                                     // the chain of a set runs through this wave
-    f32x4 r = {1.f, 0.f, 1.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int k = (2 * I + i) & 31;
-      ppk[i] = simg[k * 64 + k]; qqk[i] = simg[(32 + k) * 64 + 32 + k]; pqk[i] = simg[k * 64 + 32 + k];   // set 0 pairs k with 32 + k
-      float c, s, off, sig;
-      jacobi_rotation(ppk[i], qqk[i], pqk[i], floor_m, c, s, off, sig);
-      if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
-      r[2 * i] = c; r[2 * i + 1] = s;
-    }
-    *reinterpret_cast<f32x4*>(xb + a_csw) = r;
-  }
-  __syncthreads();
-
-  auto assemble = [&](int buf_off) {                                   // the rim of the patch from the neighbours' slots
-    const unsigned char* sl = xb + buf_off;
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(sl + a_right);
-    const f32x2 r1 = *reinterpret_cast<const f32x2*>(sl + a_right + 16);
-    const f32x2 d0 = *reinterpret_cast<const f32x2*>(sl + a_down + 24);
-    const float d1 = *reinterpret_cast<const float*>(sl + a_down + 32);
-    const float lf = *reinterpret_cast<const float*>(sl + a_left + 36);
-    const float ul = *reinterpret_cast<const float*>(sl + a_upleft + 40);
-    R.pq[0][0] = R.pq[0][1];   R.pq[0][1] = r0[0];
-    R.Qpq[0][0] = R.Qpq[0][1]; R.Qpq[0][1] = r0[1];
-    R.Qqq[0][0] = R.Qqq[0][1]; R.Qqq[0][1] = r0[2];
-    R.pq[1][0] = R.pq[1][1];   R.pq[1][1] = r0[3];
-    R.Qpq[1][0] = R.Qpq[1][1]; R.Qpq[1][1] = r1[0];
-    R.Qqq[1][0] = R.Qqq[1][1]; R.Qqq[1][1] = r1[1];
-    R.qq[0][0] = R.qq[1][0];   R.qq[0][1] = R.qq[1][1];  R.qq[1][0] = d0[0];  R.qq[1][1] = d0[1];
-    const float o10 = R.qp[1][0];
-    R.qp[0][0] = lf;  R.qp[0][1] = o10;  R.qp[1][1] = d1;  R.qp[1][0] = ul;
-  };
-
-  auto body = [&](auto CURC, auto INC) {
-    constexpr int CUR = decltype(CURC)::value, NX = CUR ^ 1;
-    constexpr bool IN = decltype(INC)::value;
-    const f32x4 rk = *reinterpret_cast<const f32x4*>(xb + CUR * CS_B + a_k);         // (c, s) of pairs 2 I, 2 I + 1
-    const f32x2 rl0 = *reinterpret_cast<const f32x2*>(xb + CUR * CS_B + a_l0);       // of pair l0
-    const f32x4 rl12 = *reinterpret_cast<const f32x4*>(xb + CUR * CS_B + a_l1);      // of pairs l0 + 1, l0 + 2
-    if (IN) assemble(CUR * SLOTS_B);
-    const float ck[2] = {rk[0], rk[2]}, sk[2] = {rk[1], rk[3]};
-    const float cl[3] = {rl0[0], rl12[0], rl12[2]}, sl[3] = {rl0[1], rl12[1], rl12[3]};
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float c = cl[i + j], s = sl[i + j];
-        // columns (pair l) on S and Q, then rows (pair k) on S
-        const float ypp = c * R.pp[i][j] - s * R.pq[i][j], ypq = s * R.pp[i][j] + c * R.pq[i][j];
-        const float yqp = c * R.qp[i][j] - s * R.qq[i][j], yqq = s * R.qp[i][j] + c * R.qq[i][j];
-        R.pp[i][j] = ck[i] * ypp - sk[i] * yqp;  R.pq[i][j] = ck[i] * ypq - sk[i] * yqq;
-        R.qp[i][j] = sk[i] * ypp + ck[i] * yqp;  R.qq[i][j] = sk[i] * ypq + ck[i] * yqq;
-        const float a0 = R.Qpp[i][j], b0 = R.Qpq[i][j], a1 = R.Qqp[i][j], b1 = R.Qqq[i][j];
-        R.Qpp[i][j] = c * a0 - s * b0;  R.Qpq[i][j] = s * a0 + c * b0;
-        R.Qqp[i][j] = c * a1 - s * b1;  R.Qqq[i][j] = s * a1 + c * b1;
-      }
-    if (PWAVE) {
-      // pairs k = 2 I + i after this set (closed form from registers); the partner diagonal of the next set is the q
-      // diagonal pair k + 1 has just produced (own pair 1 for i = 0, pair 0 of lane I + 1 for i = 1); the next pivot
-      // element is this lane's own freshly rotated cell (i, 0)
-      float ppn[2], qqn[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float c2 = ck[i] * ck[i], s2 = sk[i] * sk[i], cs2 = 2.f * ck[i] * sk[i];
-        ppn[i] = c2 * ppk[i] - cs2 * pqk[i] + s2 * qqk[i];
-        qqn[i] = s2 * ppk[i] + cs2 * pqk[i] + c2 * qqk[i];
-      }
-      // lane I reads lane I + 1 of its 16-lane row (DPP row_ror:15: no LDS round trip on the chain)
-      const int q0 = __builtin_bit_cast(int, qqn[0]);
-      const float nb = DPP ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(q0, q0, 0x12F /* row_ror:15 */, 0xF, 0xF, false))
-                           : __shfl(qqn[0], (t & 48) | ((t + 1) & 15), 64);      // (A-B: the same through ds_bpermute)
-      ppk[0] = ppn[0]; qqk[0] = qqn[1]; pqk[0] = R.pq[0][0];
-      ppk[1] = ppn[1]; qqk[1] = nb;     pqk[1] = R.pq[1][0];
-      f32x4 r;
-      bool rot[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float c, s;
-        rot[i] = jacobi_rotation_cs(ppk[i], qqk[i], pqk[i], c, s);
-        r[2 * i] = c; r[2 * i + 1] = s;
-      }
-      *reinterpret_cast<f32x4*>(xb + NX * CS_B + a_csw) = r;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float off, sig;
-        jacobi_rotation_stats(ppk[i], qqk[i], pqk[i], floor_m, rot[i], off, sig);
-        if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
-      }
-    }
-    unsigned char* so = xb + NX * SLOTS_B + a_own;
-    *reinterpret_cast<f32x4*>(so) = f32x4{R.pq[0][0], R.Qpq[0][0], R.Qqq[0][0], R.pq[1][0]};
-    *reinterpret_cast<f32x4*>(so + 16) = f32x4{R.Qpq[1][0], R.Qqq[1][0], R.qq[0][0], R.qq[0][1]};
-    *reinterpret_cast<f32x4*>(so + 32) = f32x4{R.qp[0][0], R.qp[1][1], R.qp[0][1], 0.f};
-    __syncthreads();
-  };
-  using C0 = std::integral_constant<int, 0>;
-  using C1 = std::integral_constant<int, 1>;
-  body(C0{}, std::false_type{});                                       // set 0: the patch is as loaded
-#pragma unroll 1
-  for (int s = 1; s < 31; s += 2) {
-    body(C1{}, std::true_type{});
-    body(C0{}, std::true_type{});
-  }
-  body(C1{}, std::true_type{});                                        // set 31
-  assemble(0);                                                         // back in the arrangement of set 0
-  if (PWAVE) __builtin_amdgcn_s_setprio(0);
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Strips: the same register-resident pair problem with an UNEVEN split of the cells, written after the first
@@ -438,22 +305,49 @@ __device__ __forceinline__ void cross_sets(Patch& R, unsigned char* xb, const fl
 // Exchange per lane and set: 2 W + 3 floats -- qq[0..W) and qp[0..W) to lane k - 1 (qp[W-1] to the next strip's),
 // {pq, Qpq, Qqq} of the first column to the previous strip.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ constexpr int strip_w(int sg) { return sg < 2 ? 1 : 5; }
-__device__ constexpr int strip_d0(int sg) { return sg < 2 ? sg : 2 + 5 * (sg - 2); }
-// one exchange buffer: QQ4 f32x4[256] (qq of columns 0..3) | QP4 f32x4[256] (qp 0..3) | PQ f32x2[256] ({pq, Qpq} of column 0)
-// | E[3][256] floats (qq of column 4, qp of the LAST column, Qqq of column 0)
-constexpr int SX_QQ4 = 0, SX_QP4 = 4096, SX_PQ = 8192, SX_E = 10240, SX_BUF = 13312;
-constexpr int SX_CS = 2 * SX_BUF;              // CS[2][32] float2 (c, s)
-constexpr int SX_DUMMY = SX_CS + 2 * 256;      // absorbs the (c, s) / log stores of the lanes that own no pair
-constexpr int SX_BYTES = SX_DUMMY + 256 + 16;  // (the (c, s) stores add the ping-pong offset to the dummy address as well)
+// Two splits of the 32 columns over half-waves (strips), LAY:
+//   0   8 strips on 4 waves (256 threads): 1, 1 | 5 x 6
+//   1  16 strips on 8 waves (512 threads): 1, 1 | 3, 3 | 2 x 12 -- two waves per SIMD: a wave's LDS and transcendental
+//      latencies hide behind its SIMD partner, and no wave carries more than three cells
+template <int LAY> struct Lay;
+template <> struct Lay<0> {
+  static constexpr int NS = 8, NTD = 256;
+  __device__ static constexpr int w(int sg) { return sg < 2 ? 1 : 5; }
+  __device__ static constexpr int d0(int sg) { return sg < 2 ? sg : 2 + 5 * (sg - 2); }
+  // one exchange buffer: QQ4 f32x4[256] (qq of columns 0..3) | QP4 f32x4[256] (qp 0..3) | PQ f32x2[256] ({pq, Qpq} of column
+  // 0) | E[3][256] floats (qq of column 4, qp of the LAST column, Qqq of column 0)
+  static constexpr int QQ4 = 0, QP4 = 4096, PQ = 8192, E = 10240, BUF = 13312;
+};
+template <> struct Lay<1> {
+  static constexpr int NS = 16, NTD = 512;
+  __device__ static constexpr int w(int sg) { return sg < 2 ? 1 : (sg < 4 ? 3 : 2); }
+  __device__ static constexpr int d0(int sg) { return sg < 2 ? sg : (sg < 4 ? 2 + 3 * (sg - 2) : 8 + 2 * (sg - 4)); }
+  // one exchange buffer: A f32x4[512] (qq of columns 0..2, Qqq of column 0) | B f32x4[512] (qp 0..2 -- the LAST column's is
+  // element W - 1 --, pq of column 0) | C float[512] (Qpq of column 0)
+  static constexpr int A = 0, B = 8192, C = 16384, BUF = 18432;
+};
+template <int LAY> struct Xchg {
+  static constexpr int CS = 2 * Lay<LAY>::BUF;       // CS[2][32] float2 (c, s)
+  static constexpr int DUMMY = CS + 2 * 256;         // absorbs the (c, s) / log stores of the lanes that own no pair
+  static constexpr int BYTES = DUMMY + 256 + 16;     // (the (c, s) stores add the ping-pong offset to the dummy address as well)
+};
 // The S image (64 x 64 floats, in front of the exchange area) is dead while the sets run: it becomes the LOG of the pivot
 // blocks, entry (s, k) = float4 (pp, qq, pq, rotated?) the rotation of pair k prepared during set s was derived from.  The
-// convergence statistics of those 32 x 32 rotations are evaluated AFTER the loop by all 256 lanes, four entries each
+// convergence statistics of those 32 x 32 rotations are evaluated AFTER the loop by all lanes, 1024 / NTD entries each
 // (per set on one wave they cost that wave ~310 cycles of every set: three transcendentals and their selects --
 // profiles/r04_jacobi_ts.txt -- and made it the pole of the block).
 constexpr int SX_LOG_B = 32 * 32 * 16;
 
 template <int W> struct Strip { f32x2 Xpp[W], Xpq[W], Xqp[W], Xqq[W]; };    // {S, Q} pairs; Xpq / Xqq are PHYSICAL slots
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The physical-slot arrays of a strip
+// are indexed with (j + s) mod W; written as `#pragma unroll` loops those indices are variables until the unroller has run,
+// and for W = 2, 3 the arrays were left in scratch memory (hipcc 7.2: 32-40 bytes of scratch per lane, stores and reloads
+// in every set); with j a template constant they are registers from the start.
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // one unrolled period of the set loop: sets s = 1, 2, .., LCM (mod LCM) of an iteration
 template <int LCM, class F, int... Is>
@@ -461,18 +355,20 @@ __device__ __forceinline__ void run_period(F& body, std::integer_sequence<int, I
   (body(std::integral_constant<int, (Is + 1) % LCM>{}, std::true_type{}), ...);
 }
 
-template <int W, bool PWAVE, bool PK = true>
+template <int LAY, int W, bool PWAVE>
 __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float* simg, int t, float floor_m, float& my_off, float& my_sig) {
-  constexpr int LCM = (W % 2) ? 2 * W : W;
+  using L = Lay<LAY>;
+  constexpr int LCM = (W % 2) ? 2 * W : W, NS = L::NS, SX_CS = Xchg<LAY>::CS, SX_DUMMY = Xchg<LAY>::DUMMY, SX_BUF = L::BUF;
   static_assert(30 % LCM == 0, "sets 1..30 run as whole unrolled periods");
   const int k = t & 31, sg = t >> 5;
   const bool piv = PWAVE && sg == 0;                                   // lanes 0..31 of wave 0: pair k
   const int dn = sg * 32 + ((k + 1) & 31);                             // lane (k + 1, same strip)
-  const int dl = ((sg + 7) & 7) * 32 + ((k + 1) & 31);                 // lane (k + 1, previous strip)
-  const int rt = ((sg + 1) & 7) * 32 + k;                              // lane (k, next strip)
+  const int dl = ((sg + NS - 1) % NS) * 32 + ((k + 1) & 31);           // lane (k + 1, previous strip)
+  const int rt = ((sg + 1) % NS) * 32 + k;                             // lane (k, next strip)
+  const int wprev = L::w((sg + NS - 1) % NS);                          // width of the previous strip
   int a_l[W];
 #pragma unroll
-  for (int j = 0; j < W; ++j) a_l[j] = SX_CS + ((k + strip_d0(sg) + j + 1) & 31) * 8;
+  for (int j = 0; j < W; ++j) a_l[j] = SX_CS + ((k + L::d0(sg) + j + 1) & 31) * 8;
   const int a_k = SX_CS + k * 8;
   const int a_csw = piv ? SX_CS + k * 8 : SX_DUMMY;
   // log entry of this lane's pair for the set in progress (pivot lanes; the others store into the dummy slot)
@@ -493,22 +389,43 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
   auto take_rim = [&](auto SC) {                                       // the strip's rim for set S out of buffer S & 1
     constexpr int S = decltype(SC)::value, LASTP = (W - 1 + S) % W;
     const unsigned char* b = xb + (S & 1) * SX_BUF;
-    if constexpr (W == 5) {
-      const f32x4 q4 = *reinterpret_cast<const f32x4*>(b + SX_QQ4 + dn * 16);
-      const f32x4 p4 = *reinterpret_cast<const f32x4*>(b + SX_QP4 + dn * 16);
-      const float q5 = *reinterpret_cast<const float*>(b + SX_E + dn * 4);
-      const float pl = *reinterpret_cast<const float*>(b + SX_E + 1024 + dl * 4);
-#pragma unroll
-      for (int j = 0; j < W; ++j) {
-        R.Xqq[(j + S) % W][0] = j < 4 ? q4[j] : q5;
-        R.Xqp[j][0] = j == 0 ? pl : p4[j - 1];
+    if constexpr (LAY == 0) {
+      if constexpr (W == 5) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(b + L::QQ4 + dn * 16);
+        const f32x4 p4 = *reinterpret_cast<const f32x4*>(b + L::QP4 + dn * 16);
+        const float q5 = *reinterpret_cast<const float*>(b + L::E + dn * 4);
+        const float pl = *reinterpret_cast<const float*>(b + L::E + 1024 + dl * 4);
+        static_for<W>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          R.Xqq[(j + S) % W][0] = j < 4 ? q4[j < 4 ? j : 0] : q5;
+          R.Xqp[j][0] = j == 0 ? pl : p4[j > 0 ? j - 1 : 0];
+        });
+      } else {
+        R.Xqq[0][0] = *reinterpret_cast<const float*>(b + L::QQ4 + dn * 16);
+        R.Xqp[0][0] = *reinterpret_cast<const float*>(b + L::E + 1024 + dl * 4);
       }
+      R.Xpq[LASTP] = *reinterpret_cast<const f32x2*>(b + L::PQ + rt * 8);
+      R.Xqq[LASTP][1] = *reinterpret_cast<const float*>(b + L::E + 2048 + rt * 4);
     } else {
-      R.Xqq[0][0] = *reinterpret_cast<const float*>(b + SX_QQ4 + dn * 16);
-      R.Xqp[0][0] = *reinterpret_cast<const float*>(b + SX_E + 1024 + dl * 4);
+      const float pl = *reinterpret_cast<const float*>(b + L::B + dl * 16 + (wprev - 1) * 4);
+      if constexpr (W > 1) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(b + L::A + dn * 16);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + L::B + dn * 16);
+        static_for<W>([&](auto J) {
+          constexpr int j = decltype(J)::value;
+          R.Xqq[(j + S) % W][0] = a4[j];
+          R.Xqp[j][0] = j == 0 ? pl : b4[j > 0 ? j - 1 : 0];
+        });
+      } else {
+        R.Xqq[0][0] = *reinterpret_cast<const float*>(b + L::A + dn * 16);
+        R.Xqp[0][0] = pl;
+      }
+      f32x2 pqin;
+      pqin[0] = *reinterpret_cast<const float*>(b + L::B + rt * 16 + 12);
+      pqin[1] = *reinterpret_cast<const float*>(b + L::C + rt * 4);
+      R.Xpq[LASTP] = pqin;
+      R.Xqq[LASTP][1] = *reinterpret_cast<const float*>(b + L::A + rt * 16 + 12);
     }
-    R.Xpq[LASTP] = *reinterpret_cast<const f32x2*>(b + SX_PQ + rt * 8);
-    R.Xqq[LASTP][1] = *reinterpret_cast<const float*>(b + SX_E + 2048 + rt * 4);
   };
 
 #ifdef JACOBI_TS
@@ -522,33 +439,22 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
 #endif
     const f32x2 rk = *reinterpret_cast<const f32x2*>(xb + CUR * 256 + a_k);
     f32x2 rl[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) rl[j] = *reinterpret_cast<const f32x2*>(xb + CUR * 256 + a_l[j]);
+    static_for<W>([&](auto J) { constexpr int j = decltype(J)::value; rl[j] = *reinterpret_cast<const f32x2*>(xb + CUR * 256 + a_l[j]); });
     if (IN) take_rim(SC);
     const float ck = rk[0], sk = rk[1];
     float nqq[W], nqp[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-      const int P = (j + S) % W;
+    static_for<W>([&](auto J) {
+      constexpr int j = decltype(J)::value, P = (j + S) % W;
       const float c = rl[j][0], s = rl[j][1];
       // columns (pair l) on the {S, Q} pairs as packed arithmetic, then rows (pair k) on the S halves
-      f32x2 yp, yq, yqp, yqq;
-      if constexpr (PK) {
-        yp = c * R.Xpp[j] - s * R.Xpq[P];  yq = s * R.Xpp[j] + c * R.Xpq[P];
-        yqp = c * R.Xqp[j] - s * R.Xqq[P]; yqq = s * R.Xqp[j] + c * R.Xqq[P];
-      } else {                                                         // (A-B: the same element by element)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          yp[h] = c * R.Xpp[j][h] - s * R.Xpq[P][h];  yq[h] = s * R.Xpp[j][h] + c * R.Xpq[P][h];
-          yqp[h] = c * R.Xqp[j][h] - s * R.Xqq[P][h]; yqq[h] = s * R.Xqp[j][h] + c * R.Xqq[P][h];
-        }
-      }
+      const f32x2 yp = c * R.Xpp[j] - s * R.Xpq[P], yq = s * R.Xpp[j] + c * R.Xpq[P];
+      const f32x2 yqp = c * R.Xqp[j] - s * R.Xqq[P], yqq = s * R.Xqp[j] + c * R.Xqq[P];
       f32x2 npp = yp, npq = yq;
       npp[0] = ck * yp[0] - sk * yqp[0];  npq[0] = ck * yq[0] - sk * yqq[0];
       nqp[j] = sk * yp[0] + ck * yqp[0];  nqq[j] = sk * yq[0] + ck * yqq[0];
       R.Xpp[j] = npp;  R.Xpq[P] = npq;
       R.Xqp[j][1] = yqp[1];  R.Xqq[P][1] = yqq[1];
-    }
+    });
     constexpr int P0 = S % W;                                          // physical pair of column 0
     if (PWAVE) {
       // pair k after this set (closed form from registers); partner diagonal of the next set = the q diagonal pair k + 1
@@ -571,16 +477,27 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
       logw += log_step;
     }
     unsigned char* b = xb + NX * SX_BUF;
-    if constexpr (W == 5) {
-      *reinterpret_cast<f32x4*>(b + SX_QQ4 + t * 16) = f32x4{nqq[0], nqq[1], nqq[2], nqq[3]};
-      *reinterpret_cast<f32x4*>(b + SX_QP4 + t * 16) = f32x4{nqp[0], nqp[1], nqp[2], nqp[3]};
-      *reinterpret_cast<float*>(b + SX_E + t * 4) = nqq[4];
+    if constexpr (LAY == 0) {
+      if constexpr (W == 5) {
+        *reinterpret_cast<f32x4*>(b + L::QQ4 + t * 16) = f32x4{nqq[0], nqq[1], nqq[2], nqq[3]};
+        *reinterpret_cast<f32x4*>(b + L::QP4 + t * 16) = f32x4{nqp[0], nqp[1], nqp[2], nqp[3]};
+        *reinterpret_cast<float*>(b + L::E + t * 4) = nqq[4];
+      } else {
+        *reinterpret_cast<float*>(b + L::QQ4 + t * 16) = nqq[0];
+      }
+      *reinterpret_cast<float*>(b + L::E + 1024 + t * 4) = nqp[W - 1];
+      *reinterpret_cast<f32x2*>(b + L::PQ + t * 8) = R.Xpq[P0];
+      *reinterpret_cast<float*>(b + L::E + 2048 + t * 4) = R.Xqq[P0][1];
     } else {
-      *reinterpret_cast<float*>(b + SX_QQ4 + t * 16) = nqq[0];
+      // (the pairs are taken out as WHOLE values first: element reads of R.Xpq[P0] next to the float4 being assembled were
+      //  widened into one 16-byte load over two array elements, which kept the whole array in scratch memory)
+      const f32x2 pq0 = R.Xpq[P0], qq0 = R.Xqq[P0];
+      float e0 = pq0[0], e1 = pq0[1], e2 = qq0[1];
+      R4_OPAQUE(e0); R4_OPAQUE(e1); R4_OPAQUE(e2);
+      *reinterpret_cast<f32x4*>(b + L::A + t * 16) = f32x4{nqq[0], W > 1 ? nqq[W > 1 ? 1 : 0] : 0.f, W > 2 ? nqq[W > 2 ? 2 : 0] : 0.f, e2};
+      *reinterpret_cast<f32x4*>(b + L::B + t * 16) = f32x4{nqp[0], W > 1 ? nqp[W > 1 ? 1 : 0] : 0.f, W > 2 ? nqp[W > 2 ? 2 : 0] : 0.f, e0};
+      *reinterpret_cast<float*>(b + L::C + t * 4) = e1;
     }
-    *reinterpret_cast<float*>(b + SX_E + 1024 + t * 4) = nqp[W - 1];
-    *reinterpret_cast<f32x2*>(b + SX_PQ + t * 8) = R.Xpq[P0];
-    *reinterpret_cast<float*>(b + SX_E + 2048 + t * 4) = R.Xqq[P0][1];
 #ifdef JACOBI_TS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     busy += __builtin_amdgcn_s_memtime() - ts0;                        // release of the previous barrier -> arrival at this one
@@ -596,51 +513,51 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
   // the statistics of the 32 x 32 logged rotations (the last set's are those of a rotation that is never applied: the
   // state of the pivots after the step), four per lane
 #pragma unroll
-  for (int i = 0; i < SX_LOG_B / 16 / NT; ++i) {
-    const f32x4 e = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(simg) + (t + i * NT) * 16);
+  for (int i = 0; i < SX_LOG_B / 16 / L::NTD; ++i) {
+    const f32x4 e = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(simg) + (t + i * L::NTD) * 16);
     float off, sig;
     jacobi_rotation_stats(e[0], e[1], e[2], floor_m, e[3] != 0.f, off, sig);
     my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig);
   }
 #ifdef JACOBI_TS
-  if ((t & 63) == 0 && blockIdx.x < 8192) jac_busy[blockIdx.x * 4 + (t >> 6)] = busy;
+  if ((t & 63) == 0 && blockIdx.x < 8192) jac_busy[blockIdx.x * 8 + (t >> 6)] = busy;
 #endif
 }
 
 // gather -> sets -> scatter for the lanes of one wave (strip width W); contains the barriers of the set loop and one more
-template <int W, bool PWAVE, bool PK = true>
+template <int LAY, int W, bool PWAVE>
 __device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned char* xb, int t, float floor_m, float& my_off, float& my_sig) {
   constexpr int M2 = 64, B = 32;
   const int k = t & 31, sg = t >> 5;
   Strip<W> R;
   int la[W];
-#pragma unroll
-  for (int j = 0; j < W; ++j) {
-    const int l = (k + strip_d0(sg) + j + 1) & 31;
+  static_for<W>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    const int l = (k + Lay<LAY>::d0(sg) + j + 1) & 31;
     la[j] = l;
     const float one = k == l ? 1.f : 0.f;
     R.Xpp[j] = f32x2{simg[k * M2 + l], one};        R.Xpq[j] = f32x2{simg[k * M2 + B + l], 0.f};
     R.Xqp[j] = f32x2{simg[(B + k) * M2 + l], 0.f};  R.Xqq[j] = f32x2{simg[(B + k) * M2 + B + l], one};
-  }
-  strip_sets<W, PWAVE, PK>(R, xb, simg, t, floor_m, my_off, my_sig);
+  });
+  strip_sets<LAY, W, PWAVE>(R, xb, simg, t, floor_m, my_off, my_sig);
   __syncthreads();                                  // every lane has taken its last rim: the exchange area becomes the Q image
   constexpr int LCM = (W % 2) ? 2 * W : W, SF = 32 % LCM;
-#pragma unroll
-  for (int j = 0; j < W; ++j) {
-    const int l = la[j], P = (j + SF) % W;
+  static_for<W>([&](auto J) {
+    constexpr int j = decltype(J)::value, P = (j + SF) % W;
+    const int l = la[j];
     simg[k * M2 + l] = R.Xpp[j][0];        simg[k * M2 + B + l] = R.Xpq[P][0];
     simg[(B + k) * M2 + l] = R.Xqp[j][0];  simg[(B + k) * M2 + B + l] = R.Xqq[P][0];
     qimg[k * M2 + l] = R.Xpp[j][1];        qimg[k * M2 + B + l] = R.Xpq[P][1];
     qimg[(B + k) * M2 + l] = R.Xqp[j][1];  qimg[(B + k) * M2 + B + l] = R.Xqq[P][1];
-  }
+  });
 }
 
 // D part: the pair problem (bi, bj) of matrix m at outer step p.step_d -- 256 threads (jacobi_fused_d: 1024)
-// VAR: 0 = 2 x 2 patches (cross_sets), 1 = strips (strip_sets), 2 = strips with element-wise arithmetic (A-B)
-template <int M2, bool DPP = true, int VAR = 1>
+// LAY: the strip layout (Lay<LAY>::NTD threads per pair problem)
+template <int M2, int LAY>
 __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, float* jsm) {
-  static_assert(M2 == 64, "the patch layout is written for 64 x 64 pair problems");
-  constexpr int B = M2 / 2, NW = M2 / 16, FR = M2 * M2;
+  static_assert(M2 == 64, "the strip layouts are written for 64 x 64 pair problems");
+  constexpr int B = M2 / 2, NW = M2 / 16, FR = M2 * M2, NT = Lay<LAY>::NTD, NWAVES = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int C = p.C, nblk = C / B, npair = nblk / 2;
   int bi, bj;
@@ -729,8 +646,8 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       __syncthreads();
       JTS(2);
 #pragma unroll
-      for (int jb = 0; jb < (B / 16) * NW / (NT / 64); ++jb) {          // W = Q_g1[:, h1]^T X   (B x M2): two tiles per wave
-        const int job = wave * ((B / 16) * NW / (NT / 64)) + jb, tr = job / NW, tj = job % NW;
+      for (int jb = 0; jb < (B / 16) * NW / NWAVES; ++jb) {             // W = Q_g1[:, h1]^T X   (B x M2): 8 tiles over the waves
+        const int job = wave * ((B / 16) * NW / NWAVES) + jb, tr = job / NW, tj = job % NW;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int kk = 0; kk < M2; kk += 4)
@@ -739,7 +656,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
         for (int r = 0; r < 4; ++r) Ws[(16 * tr + 4 * lq + r) * (M2 + 1) + 16 * tj + li] = acc[r];
       }
       __syncthreads();
-      {                                                                 // crit = W Q_g2[:, h2]   (B x B): one tile per wave
+      if (wave < (B / 16) * (B / 16)) {                                 // crit = W Q_g2[:, h2]   (B x B): one tile per wave
         const int tr = wave / (B / 16), tc = wave % (B / 16);
 #pragma unroll 4
         for (int kk = 0; kk < M2; kk += 4)
@@ -757,7 +674,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
         if (r == c) my_dm = fmaxf(my_dm, fabsf(sv[i]));
       }
     }
-    if (!same) {
+    if (!same && wave < (B / 16) * (B / 16)) {
       const int tr = wave / (B / 16), tc = wave % (B / 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -772,46 +689,15 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
   float* Qimg = jsm + FR;                           // [M2][M2] floats (cross steps: epilogue only)
   JTS(4);
   if (p.step_d >= 0) {
-    if constexpr (VAR >= 1) {
-      // ---- strips: gather, 32 sets, scatter, by wave (the three branches execute the same barriers)
+    {
+      // ---- strips: gather, 32 sets, scatter, by wave (the branches execute the same barriers)
       unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + FR);
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-      if (wv == 0) strip_wave<1, true, VAR == 1>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
-      else strip_wave<5, false, VAR == 1>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
+      if (wv == 0) strip_wave<LAY, 1, true>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
+      else if (LAY == 0) strip_wave<LAY, 5, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
+      else if (wv == 1) strip_wave<LAY, 3, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
+      else strip_wave<LAY, 2, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
       JTS(5);
-    } else {
-    // ---- the patch out of the image, 32 sets, the patch back into the S and Q images
-      const int I = tid & 15, Dd = tid >> 4;
-      Patch R;
-      int ka[2], la[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ka[i] = 2 * I + i;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int k = ka[i], l = (k + 2 * Dd + j + 1) & 31;
-          la[i][j] = l;
-          R.pp[i][j] = Simg[k * M2 + l];        R.pq[i][j] = Simg[k * M2 + B + l];
-          R.qp[i][j] = Simg[(B + k) * M2 + l];  R.qq[i][j] = Simg[(B + k) * M2 + B + l];
-          R.Qpp[i][j] = k == l ? 1.f : 0.f;  R.Qqq[i][j] = R.Qpp[i][j];
-          R.Qpq[i][j] = 0.f;  R.Qqp[i][j] = 0.f;
-        }
-      }
-      unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + FR);
-      if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) cross_sets<true, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
-      else cross_sets<false, DPP>(R, xb, Simg, tid, floor_m, my_off, my_sig);
-      JTS(5);
-      __syncthreads();                                // every lane has taken its last rim: the exchange area becomes the Q image
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int k = ka[i], l = la[i][j];
-          Simg[k * M2 + l] = R.pp[i][j];        Simg[k * M2 + B + l] = R.pq[i][j];
-          Simg[(B + k) * M2 + l] = R.qp[i][j];  Simg[(B + k) * M2 + B + l] = R.qq[i][j];
-          Qimg[k * M2 + l] = R.Qpp[i][j];       Qimg[k * M2 + B + l] = R.Qpq[i][j];
-          Qimg[(B + k) * M2 + l] = R.Qqp[i][j]; Qimg[(B + k) * M2 + B + l] = R.Qqq[i][j];
-        }
     }
     __syncthreads();
     constexpr int NCH = M2 / 32;
@@ -884,6 +770,7 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
   constexpr int B = M2 / 2, PITCH = M2 + 1, NW = M2 / 16, FR = M2 * M2, NV = FR / 4 / NT;
   static_assert(NT / 64 == NW, "one 16-row strip per wave");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid >= NT) return;                         // launched beside 512-thread pair problems: waves 4..7 have no part (before any barrier)
   const int C = p.C, nblk = C / B, npair = nblk / 2;
   const int n_off = npair * (npair - 1) / 2;
   const size_t cc = (size_t)C * C;

@@ -510,7 +510,7 @@ __global__ void cov_finish_kernel(const float* partial, const float* scale, floa
 // ---------------------------------------------------------------------------
 #ifdef JACOBI_TS
 __device__ unsigned long long jac_ts[8192 * 10];
-__device__ unsigned long long jac_busy[8192 * 4];      // strip_sets: cycles each wave spent between the barriers of its 32 sets
+__device__ unsigned long long jac_busy[8192 * 8];      // strip_sets: cycles each wave spent between the barriers of its 32 sets
 #define JTS(slot) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { jac_ts[blockIdx.x * 10 + (slot)] = __builtin_amdgcn_s_memtime(); if ((slot) == 0) jac_ts[blockIdx.x * 10 + 8] = wall_clock64(); if ((slot) == 7) jac_ts[blockIdx.x * 10 + 9] = wall_clock64(); } } while (0)
 #else
 #define JTS(slot) do {} while (0)
@@ -962,14 +962,14 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_
 }
 
 namespace r4 {
-template <int M2>
+template <int M2, int LAY>
 static size_t fused_lds(int has_d, int has_u, int first, int step_d) {
   constexpr int B = M2 / 2;
   size_t need = 0;
   if (has_d) {
     if (step_d < 0) need = jacobi_diag_lds<M2>(-1, true);                               // intra sets: two {S, Q} images
     else {
-      need = (size_t)M2 * M2 * sizeof(float) + std::max(XCHG_B, SX_BYTES);              // S image, exchange area
+      need = (size_t)M2 * M2 * sizeof(float) + Xchg<LAY>::BYTES;                       // S image, exchange area
       need = std::max(need, (size_t)2 * M2 * M2 * sizeof(float));                       // S and Q images of the epilogue
       if (!first) need = std::max(need, (size_t)(M2 * (M2 + 1) + 2 * M2 * (B + 1) + B * (M2 + 1)) * sizeof(float));
     }
@@ -981,8 +981,8 @@ static size_t fused_lds(int has_d, int has_u, int first, int step_d) {
 
 
 // grid: [nmat * npair pair problems (if has_d)] [ntask * nmat update tasks, task-major (if has_u)]; 256 threads
-template <int M2, bool DPP, int VAR>
-__global__ __launch_bounds__(r4::NT, 3) void jacobi_fused4_kernel(JacobiFusedArgs p) {
+template <int M2, int LAY>
+__global__ __launch_bounds__(r4::Lay<LAY>::NTD, LAY ? 4 : 3) void jacobi_fused4_kernel(JacobiFusedArgs p) {
   extern __shared__ __attribute__((aligned(16))) float jsm[];
   constexpr int B = M2 / 2;
   const int npair = p.C / B / 2;
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(r4::NT, 3) void jacobi_fused4_kernel(JacobiFusedArg
   if (b < n_d) {
     const int m = b / npair, g = b % npair;
     JTS(0);
-    r4::fused_d<M2, DPP, VAR>(p, m, g, jsm);
+    r4::fused_d<M2, LAY>(p, m, g, jsm);
   } else {
     b -= n_d;
     const int task = b / p.nmat, m = b % p.nmat;
@@ -1401,6 +1401,11 @@ static JacobiHost* jacobi_host() {
   return &h;
 }
 
+// Pair-problem kernel of the 64-wide block pairs: 1 = strips over 4 waves (256 threads; the product), 2 = strips over 8 waves
+// (512 threads), 0 = the round-3 kernel (LDS-resident {S, Q} image, 1024 threads).  A-B switch of a tuning build
+// (WCT_JACOBI_R4); the product build compiles mode 1 only.  Measured (profiles/r04_jacobi_ab.txt), eigensolver ms per step at
+// batch 32 / 8 / 1: mode 1 14.4 / 7.6 / 6.0, mode 2 16.2 / 7.7 / 6.1 (same per-SIMD instruction load, more exchange
+// instructions), mode 0 17.1 / 8.0 / 6.4.
 static int jacobi_r4_mode() {
   static const int on = tune_int("WCT_JACOBI_R4", 1);
   return on;
@@ -1424,16 +1429,19 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
   static const int dbg = tune_int("WCT_JACOBI_DBG", 0);
   a.dbg = dbg;
   const unsigned grid = (has_d ? G.nmat * npair : 0) + (has_u ? G.nmat * ntask : 0);
-  // round 4 (M2 = 64): pair problems resident in registers, 256 threads per pair problem and per update task (namespace
-  // r4): 1 x W strips (default).  A-B switches: WCT_JACOBI_R4=0 selects the round-3 kernel (LDS-resident {S, Q} image, 1024
-  // threads), =2 the register kernel with 2 x 2 patches
+  // round 4 (M2 = 64): pair problems resident in registers (namespace r4, csrc/jacobi_dev.h); the 32-wide block pairs of
+  // C <= 128 keep the round-3 kernel
   const int r4m = M2 == 64 ? jacobi_r4_mode() : 0;
   if constexpr (M2 == 64) {
-    if (r4m == 2) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true, 0>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
-    else if (r4m == 3) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true, 2>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
-    else if (r4m) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, true, 1>), dim3(grid), dim3(r4::NT), r4::fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+#ifdef WCT_TUNING
+    if (r4m == 2) hipLaunchKernelGGL((jacobi_fused4_kernel<M2, 1>), dim3(grid), dim3(r4::Lay<1>::NTD), (r4::fused_lds<M2, 1>(has_d, has_u, first, step_d)), G.stream, a);
+    else if (r4m == 0) hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+    else
+#endif
+    hipLaunchKernelGGL((jacobi_fused4_kernel<M2, 0>), dim3(grid), dim3(r4::Lay<0>::NTD), (r4::fused_lds<M2, 0>(has_d, has_u, first, step_d)), G.stream, a);
+  } else {
+    hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
   }
-  if (!r4m) hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
 #ifdef JACOBI_TS
   if (has_d && !first && step_d >= 0 && M2 == 64) {
     static int nlaunch = 0, last_nmat = 0;
@@ -1452,9 +1460,8 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
     }
     if (nlaunch == 0) {
       int occ = 0;
-      if (r4m) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, jacobi_fused4_kernel<64, true, 1>, r4::NT, r4::fused_lds<64>(has_d, has_u, first, step_d));
-      else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, jacobi_fused_kernel<M2>, NT, jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
-      printf("jacobi_ts: occupancy API says %d blocks of %d threads per CU with %zu B of LDS\n", occ, r4m ? r4::NT : NT, r4m ? r4::fused_lds<64>(has_d, has_u, first, step_d) : jacobi_fused_lds<M2>(has_d, has_u, first, step_d));
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, jacobi_fused4_kernel<64, 0>, r4::Lay<0>::NTD, r4::fused_lds<64, 0>(has_d, has_u, first, step_d));
+      printf("jacobi_ts: occupancy API says %d blocks of %d threads per CU with %zu B of LDS\n", occ, r4::Lay<0>::NTD, r4::fused_lds<64, 0>(has_d, has_u, first, step_d));
     }
     span += (double)(hi - lo);
     if (nlaunch == 40) {
@@ -1464,15 +1471,15 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
       printf("jacobi_ts nmat %d launch 40: block start offsets (10 ns ticks) p0 %llu p25 %llu p50 %llu p75 %llu p90 %llu p100 %llu | end offsets p0 %llu p50 %llu p100 %llu\n", G.nmat,
              st0[0], st0[nb / 4], st0[nb / 2], st0[3 * nb / 4], st0[9 * nb / 10], st0[nb - 1], en0[0], en0[nb / 2], en0[nb - 1]);
     }
-    if (r4m == 1 || r4m == 3) {
-      static unsigned long long hb[8192 * 4];
-      static double bs[4] = {0, 0, 0, 0};
+    if (r4m) {
+      static unsigned long long hb[8192 * 8];
+      static double bs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       if (nlaunch == 0) for (double& v : bs) v = 0;
       (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(jac_busy), sizeof(hb));
-      for (int i = 0; i < nb; ++i) for (int w = 0; w < 4; ++w) bs[w] += (double)hb[i * 4 + w] / nb;
+      for (int i = 0; i < nb; ++i) for (int w = 0; w < 8; ++w) bs[w] += (double)hb[i * 8 + w] / nb;
       if ((nlaunch + 1) % 32 == 0)
-        printf("jacobi_ts nmat %d: cycles between barrier release and next arrival, summed over the 32 sets, by wave: pivots %.0f | strips %.0f %.0f %.0f\n",
-               G.nmat, bs[0] / (nlaunch + 1), bs[1] / (nlaunch + 1), bs[2] / (nlaunch + 1), bs[3] / (nlaunch + 1));
+        printf("jacobi_ts nmat %d: cycles between barrier release and next arrival, summed over the 32 sets, by wave: pivots %.0f | strips %.0f %.0f %.0f %.0f %.0f %.0f %.0f\n",
+               G.nmat, bs[0] / (nlaunch + 1), bs[1] / (nlaunch + 1), bs[2] / (nlaunch + 1), bs[3] / (nlaunch + 1), bs[4] / (nlaunch + 1), bs[5] / (nlaunch + 1), bs[6] / (nlaunch + 1), bs[7] / (nlaunch + 1));
     }
     if (++nlaunch % 32 == 0) {
       printf("jacobi_ts nmat %d (%d launches): state %.0f | loads->LDS %.0f | crit %.0f | image %.0f | sets %.0f | stores issued %.0f | drained %.0f | first start -> last end %.0f wall-clock ticks (100 MHz) (others: s_memtime ticks)\n",
