@@ -724,6 +724,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     constexpr int PITCH = M2 + 1, KB = (M2 / 2) * (M2 / 2) / NT;
     float* DO = jsm + 4 * M2 * PITCH;
     const int cur = jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, floor_m, my_off, my_sig);
+    JTS(5);
     const f32x2* img = SQ + cur * M2 * PITCH;
     constexpr int NCH = M2 / 32;
     for (int e = tid; e < FR; e += NT) So[e] = img[(e / M2) * PITCH + (e % M2)][0];

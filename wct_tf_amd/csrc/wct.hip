@@ -1443,7 +1443,8 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
     hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
   }
 #ifdef JACOBI_TS
-  if (has_d && !first && step_d >= 0 && M2 == 64) {
+  static const int ts_intra = getenv("WCT_TS_INTRA") != nullptr;      // (-DJACOBI_TS builds only) summarise the intra steps instead
+  if (has_d && M2 == 64 && (ts_intra ? step_d < 0 : (!first && step_d >= 0))) {
     static int nlaunch = 0, last_nmat = 0;
     static double sum[8] = {0}, span = 0;
     if (G.nmat != last_nmat) { nlaunch = 0; span = 0; for (double& v : sum) v = 0; last_nmat = G.nmat; }
