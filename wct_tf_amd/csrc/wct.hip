@@ -1701,17 +1701,51 @@ __device__ __forceinline__ float spectral_entry(float dp, float dq, float e, boo
   return e * fk / fmaxf(dk - dd, 2.f * fabsf(e));
 }
 
-__global__ void spectral_matrix_kernel(const float* A, float* G, int C, size_t stride, int kind, float shift, int correct) {
-  const int m = blockIdx.y;
-  const size_t cc = (size_t)C * C;
+// The three elementwise passes over a matrix in 64 x 64 TILES (round 4).  Written element by element (round 3) every
+// output read two diagonal entries (a gather with stride C + 1: one cache line per thread) and the mirrored entry
+// (a column walk), ~1.4 ms per 32-pair step for three kernels that move 100 MB each.  A block now parks the two
+// diagonal segments of its tile and the MIRROR tile in LDS (rows loaded coalesced, read transposed), so every global
+// access is a coalesced 16-byte row piece.  Per element the arithmetic is what it was, in the same order.
+struct SpectralTile {
+  float dp[64], dq[64];          // diagonal entries of the tile's rows / columns
+  float mt[64][65];              // mirror tile: mt[c][r] = A[q0 + c][p0 + r]
+};
+__device__ __forceinline__ void spectral_tile_load(SpectralTile& t, const float* Am, int C, int p0, int q0, int tid) {
+  if (tid < 64) t.dp[tid] = p0 + tid < C ? Am[(size_t)(p0 + tid) * C + p0 + tid] : 0.f;
+  else if (tid < 128) t.dq[tid - 64] = q0 + tid - 64 < C ? Am[(size_t)(q0 + tid - 64) * C + q0 + tid - 64] : 0.f;
+  const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = q0 + ty * 4 + i, c = p0 + tx * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < C && c < C) v = *reinterpret_cast<const f32x4*>(Am + (size_t)r * C + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t.mt[ty * 4 + i][tx * 4 + j] = v[j];
+  }
+}
+
+// grid (C / 64, C / 64, nbatch): tile rows p0 = 64 blockIdx.y, columns q0 = 64 blockIdx.x
+__global__ __launch_bounds__(256) void spectral_matrix_kernel(const float* A, float* G, int C, size_t stride, int kind, float shift, int correct) {
+  __shared__ SpectralTile t;
+  const int m = blockIdx.z, p0 = blockIdx.y * 64, q0 = blockIdx.x * 64, tid = threadIdx.x;
   const float* Am = A + m * stride;
   float* Gm = G + m * stride;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x) {
-    const int p = (int)(i / C), q = (int)(i % C);
-    const float dp = Am[(size_t)p * C + p], dq = Am[(size_t)q * C + q];
-    // the two triangles agree to round-off; their mean keeps G exactly symmetric
-    const float e = correct ? 0.5f * (Am[i] + Am[(size_t)q * C + p]) : 0.f;
-    Gm[i] = spectral_entry(dp, dq, e, p == q, kind, shift);
+  spectral_tile_load(t, Am, C, p0, q0, tid);
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = ty * 4 + i, p = p0 + pl, q = q0 + tx * 4;
+    if (p >= C || q >= C) continue;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(Am + (size_t)p * C + q);
+    f32x4 g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // the two triangles agree to round-off; their mean keeps G exactly symmetric
+      const float e = correct ? 0.5f * (a[j] + t.mt[tx * 4 + j][pl]) : 0.f;
+      g[j] = spectral_entry(t.dp[pl], t.dq[tx * 4 + j], e, p == q + j, kind, shift);
+    }
+    *reinterpret_cast<f32x4*>(Gm + (size_t)p * C + q) = g;
   }
 }
 
@@ -1726,28 +1760,42 @@ __global__ void spectral_matrix_kernel(const float* A, float* G, int C, size_t s
 // (checked against an exact eigendecomposition in NumPy: the error of f(D + E) drops from ~r^2 to ~r^3).  Only the block
 // of kept eigenvalues takes part: a dropped direction's couplings are bounded by sqrt(1e-5 d_p) tol and enter squared.
 // It lets the sweeps stop one sweep earlier for the same transform error (profiles/r03_eig_calibration.txt).
-__global__ void spectral_prep2_kernel(const float* A, float* N, float* R, float* Pm, int C, size_t stride, int kind, float shift) {
-  const int m = blockIdx.y;
+__global__ __launch_bounds__(256) void spectral_prep2_kernel(const float* A, float* N, float* R, float* Pm, int C, size_t stride, int kind, float shift) {
+  __shared__ SpectralTile t;
+  const int m = blockIdx.z, p0 = blockIdx.y * 64, q0 = blockIdx.x * 64, tid = threadIdx.x;
   const size_t cc = (size_t)C * C;
   const float* Am = A + m * stride;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x) {
-    const int p = (int)(i / C), k = (int)(i % C);
-    const float dp = Am[(size_t)p * C + p], dk = Am[(size_t)k * C + k];
-    float n = 0.f, r = 0.f, pm = 0.f;
-    if (p != k && dp > 1e-5f && dk > 1e-5f) {
-      const float e = 0.5f * (Am[i] + Am[(size_t)k * C + p]);
-      const float sp = sqrtf(dp + shift), sk = sqrtf(dk + shift);
-      n = e / (sp + sk);
-      r = e / sk;
-      pm = n / sk;
+  spectral_tile_load(t, Am, C, p0, q0, tid);
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = ty * 4 + i, p = p0 + pl, k0 = q0 + tx * 4;
+    if (p >= C || k0 >= C) continue;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(Am + (size_t)p * C + k0);
+    const float dp = t.dp[pl];
+    f32x4 n4 = {0.f, 0.f, 0.f, 0.f}, r4 = n4, p4 = n4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dk = t.dq[tx * 4 + j];
+      if (p != k0 + j && dp > 1e-5f && dk > 1e-5f) {
+        const float e = 0.5f * (a[j] + t.mt[tx * 4 + j][pl]);
+        const float sp = sqrtf(dp + shift), sk = sqrtf(dk + shift);
+        n4[j] = e / (sp + sk);
+        r4[j] = e / sk;
+        p4[j] = n4[j] / sk;
+      }
     }
-    N[m * cc + i] = n;
-    if (kind == 0) { R[m * cc + i] = r; Pm[m * cc + i] = pm; }
+    const size_t o = m * cc + (size_t)p * C + k0;
+    *reinterpret_cast<f32x4*>(N + o) = n4;
+    if (kind == 0) { *reinterpret_cast<f32x4*>(R + o) = r4; *reinterpret_cast<f32x4*>(Pm + o) = p4; }
   }
 }
 
-__global__ void spectral_add2_kernel(const float* A, float* G, const float* X1, const float* X2, int C, size_t stride, int kind, float shift) {
-  const int m = blockIdx.y;
+__global__ __launch_bounds__(256) void spectral_add2_kernel(const float* A, float* G, const float* X1, const float* X2, int C, size_t stride, int kind, float shift) {
+  __shared__ float dps[64], dqs[64];
+  __shared__ float x1t[64][65], x2t[64][65];       // mirror tiles of X1 (kind 0 only), X2
+  const int m = blockIdx.z, p0 = blockIdx.y * 64, q0 = blockIdx.x * 64, tid = threadIdx.x;
   const size_t cc = (size_t)C * C;
   const float* Am = A + m * stride;
   float* Gm = G + m * stride;
@@ -1755,21 +1803,47 @@ __global__ void spectral_add2_kernel(const float* A, float* G, const float* X1, 
   // threshold (jacobi_resid_kernel weighs its residual accordingly): around the cut-off sit the noise directions of
   // rank-deficient covariances, whose mutual couplings never become small, and a second-order sum over them is noise
   int near = 0;
-  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+  for (int i = tid; i < C; i += 256) {
     const float d = fabsf(Am[(size_t)i * C + i]);
     near |= (d > 3.3e-6f) & (d < 3e-5f);
   }
   if (__syncthreads_or(near)) return;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x) {
-    const int p = (int)(i / C), q = (int)(i % C);
-    const float dp = Am[(size_t)p * C + p], dq = Am[(size_t)q * C + q];
-    if (!(dp > 1e-5f && dq > 1e-5f)) continue;
-    const float sp = sqrtf(dp + shift), sq = sqrtf(dq + shift);
-    const size_t t = (size_t)q * C + p;
-    float l2;
-    if (kind == 1) l2 = -0.5f * (X2[m * cc + i] + X2[m * cc + t]) / (sp + sq);
-    else l2 = (0.5f * (X1[m * cc + i] + X1[m * cc + t]) + 0.25f * (sp + sq) * (X2[m * cc + i] + X2[m * cc + t])) / (sp * sq * (sp + sq));
-    Gm[i] += l2;
+  if (tid < 64) dps[tid] = p0 + tid < C ? Am[(size_t)(p0 + tid) * C + p0 + tid] : 0.f;
+  else if (tid < 128) dqs[tid - 64] = q0 + tid - 64 < C ? Am[(size_t)(q0 + tid - 64) * C + q0 + tid - 64] : 0.f;
+  const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = q0 + ty * 4 + i, c = p0 + tx * 4;
+    f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1;
+    if (r < C && c < C) {
+      v2 = *reinterpret_cast<const f32x4*>(X2 + m * cc + (size_t)r * C + c);
+      if (kind == 0) v1 = *reinterpret_cast<const f32x4*>(X1 + m * cc + (size_t)r * C + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x2t[ty * 4 + i][tx * 4 + j] = v2[j]; x1t[ty * 4 + i][tx * 4 + j] = v1[j]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = ty * 4 + i, p = p0 + pl, q = q0 + tx * 4;
+    if (p >= C || q >= C) continue;
+    const size_t o = (size_t)p * C + q;
+    const f32x4 x2 = *reinterpret_cast<const f32x4*>(X2 + m * cc + o);
+    f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
+    if (kind == 0) x1 = *reinterpret_cast<const f32x4*>(X1 + m * cc + o);
+    f32x4 g = *reinterpret_cast<const f32x4*>(Gm + o);
+    const float dp = dps[pl];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dq = dqs[tx * 4 + j];
+      if (!(dp > 1e-5f && dq > 1e-5f)) continue;
+      const float sp = sqrtf(dp + shift), sq = sqrtf(dq + shift);
+      float l2;
+      if (kind == 1) l2 = -0.5f * (x2[j] + x2t[tx * 4 + j][pl]) / (sp + sq);
+      else l2 = (0.5f * (x1[j] + x1t[tx * 4 + j][pl]) + 0.25f * (sp + sq) * (x2[j] + x2t[tx * 4 + j][pl])) / (sp * sq * (sp + sq));
+      g[j] += l2;
+    }
+    *reinterpret_cast<f32x4*>(Gm + o) = g;
   }
 }
 
@@ -1795,11 +1869,11 @@ static float jacobi_tol_fn() {
 static int launch_spectral_function(const float* A, const float* V, float* G, float* X, float* out, int C, int nbatch,
                                     size_t stride, size_t out_stride, int kind, float shift, hipStream_t s, float* scratch2 = nullptr) {
   const size_t cc = (size_t)C * C;
-  const unsigned ew = (unsigned)(cc >= 65536 ? 64 : (cc + 255) / 256);
-  hipLaunchKernelGGL(spectral_matrix_kernel, dim3(ew, nbatch), dim3(256), 0, s, A, G, C, stride, kind, shift, eig_correct_enabled());
+  const dim3 tiles(cdiv(C, 64), cdiv(C, 64), nbatch);
+  hipLaunchKernelGGL(spectral_matrix_kernel, tiles, dim3(256), 0, s, A, G, C, stride, kind, shift, eig_correct_enabled());
   if (scratch2 && eig_correct_enabled() >= 2) {
     float* N = scratch2; float* R = N + nbatch * cc; float* Pm = R + nbatch * cc; float* X1 = Pm + nbatch * cc; float* X2 = X1 + nbatch * cc;
-    hipLaunchKernelGGL(spectral_prep2_kernel, dim3(ew, nbatch), dim3(256), 0, s, A, N, R, Pm, C, stride, kind, shift);
+    hipLaunchKernelGGL(spectral_prep2_kernel, tiles, dim3(256), 0, s, A, N, R, Pm, C, stride, kind, shift);
     GemmArgs a = {};   // X2 = (kind 1: N, kind 0: P) N
     a.A = kind == 1 ? N : Pm; a.lda = C; a.a_kmajor = 0; a.B = N; a.ldb = C; a.b_kmajor = 1; a.sA = a.sB = cc;
     a.M = C; a.N = C; a.K = C; a.ksplit = C; a.out32 = X2; a.ldo = C; a.s_out = cc;
@@ -1809,7 +1883,7 @@ static int launch_spectral_function(const float* A, const float* V, float* G, fl
       a.A = R; a.out32 = X1;   // X1 = R N
       if ((rc2 = launch_gemm(a, 1, nbatch, s))) return rc2;
     }
-    hipLaunchKernelGGL(spectral_add2_kernel, dim3(ew, nbatch), dim3(256), 0, s, A, G, X1, X2, C, stride, kind, shift);
+    hipLaunchKernelGGL(spectral_add2_kernel, tiles, dim3(256), 0, s, A, G, X1, X2, C, stride, kind, shift);
   }
   GemmArgs g = {};   // X = V G
   g.A = V; g.lda = C; g.a_kmajor = 0; g.B = G; g.ldb = C; g.b_kmajor = 1; g.sA = g.sB = stride;
