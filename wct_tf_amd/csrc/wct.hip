@@ -482,22 +482,50 @@ __global__ __launch_bounds__(256, 2) void cov_f16x2_kernel(CovArgs p) {
 
 // cov[m] = sum_split partial / (scale_m^2 (N_m - 1)) + eps I; entries below the diagonal tiles are the
 // mirror of the computed upper tiles (BT = tile side of the partials)
-__global__ void cov_finish_kernel(const float* partial, const float* scale, float* cov, int C, int nsplit, int BT,
-                                  float inv0, float inv1, float eps, int shared_style) {
-  const int mat = blockIdx.y;             // 2*pair + side
+// (round 4: in 64 x 64 tiles -- a tile below the diagonal of the BT grid reads its mirror tile's rows, coalesced, and turns
+//  them in LDS; element by element the lower triangle walked columns of every partial.  Same sums in the same order.)
+// grid (C / 64, C / 64, 2P)
+__global__ __launch_bounds__(256) void cov_finish_kernel(const float* partial, const float* scale, float* cov, int C, int nsplit, int BT,
+                                                         float inv0, float inv1, float eps, int shared_style) {
+  __shared__ float tt[64][65];
+  const int mat = blockIdx.z;             // 2*pair + side
   if (skip_style_mat(mat, shared_style)) return;
   const size_t cc = (size_t)C * C;
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= cc) return;
-  const int r = (int)(i / C), c = (int)(i % C);
-  const size_t src = (r / BT > c / BT) ? (size_t)c * C + r : i;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const bool mirror = r0 / BT > c0 / BT;  // (uniform: BT is a multiple of 64)
   const float* pb = partial + (size_t)mat * nsplit * cc;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += pb[(size_t)k * cc + src];
   const float sc = scale[mat];
-  s *= ((mat & 1) == 0 ? inv0 : inv1) / (sc * sc);
-  if (r == c) s += eps;
-  cov[(size_t)mat * cc + i] = s;
+  const float f = ((mat & 1) == 0 ? inv0 : inv1) / (sc * sc);
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // direct: element (r0 + 4 ty + i, c0 + 4 tx ..); mirror: element (c0 + 4 ty + i, r0 + 4 tx ..) of the upper triangle
+    const int r = (mirror ? c0 : r0) + ty * 4 + i, c = (mirror ? r0 : c0) + tx * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (r < C && c < C)
+      for (int k = 0; k < nsplit; ++k) sum += *reinterpret_cast<const f32x4*>(pb + (size_t)k * cc + (size_t)r * C + c);
+    acc[i] = sum;
+  }
+  if (mirror) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tt[ty * 4 + i][tx * 4 + j] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = tt[tx * 4 + j][ty * 4 + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty * 4 + i, c = c0 + tx * 4;
+    if (r >= C || c >= C) continue;
+    f32x4 v = acc[i] * f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (r == c + j) v[j] += eps;
+    *reinterpret_cast<f32x4*>(cov + (size_t)mat * cc + (size_t)r * C + c) = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2223,7 +2251,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   // (ops.py:24,45,50), 1e-5 inside the spectral gains for wct_np (ops.py:92,114,127)
   const float eps_user = eps_in >= 0.f ? eps_in : (mode == WCT_MODE_TF ? 1e-8f : 1e-5f);
   const float eps = mode == WCT_MODE_TF ? eps_user : 0.f;
-  hipLaunchKernelGGL(cov_finish_kernel, dim3((unsigned)((cc + 255) / 256), 2 * P), dim3(256), 0, s,
+  hipLaunchKernelGGL(cov_finish_kernel, dim3(cdiv(C, 64), cdiv(C, 64), 2 * P), dim3(256), 0, s,
                      w.cov_partial, w.scale, w.A, C, w.nsplit, BT, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps, shared_style);
   }
   if (stages & WCT_STAGE_EIG) {
