@@ -117,7 +117,7 @@ def pmc_traffic(batch, size):
     """HBM bytes per conv3x3 launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
     runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read from inside this
     process, so the figure is the profile of this exact workload, not a measurement of this run; null otherwise."""
-    for tag in ('r03_final', 'r02_final', 'r01_final'):
+    for tag in ('r04_final', 'r03_final', 'r02_final', 'r01_final'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_conv3x3.json' % tag)
         if batch == PMC_BATCH and size == 512 and os.path.exists(path):
             return json.load(open(path))['hbm_bytes_per_launch_corrected'], 'profiles/%s_pmc_hbm.csv' % tag
@@ -410,10 +410,13 @@ def main():
                 'achieved_tflops': jtf, 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'frac_of_f32_mfma_peak': jtf / F32_MFMA_PEAK_TFLOPS,
                 'flops_note': 'fp32-MFMA FLOPs of the tile updates the sweeps executed (two-sided A tiles + V Q), from the sweep '
                               'counts the library reports (wct_eig_stats); the rotation sets themselves run on the VALU/LDS',
-                'bound': 'latency of the serial rotation sets (LDS write path) + fp32-MFMA tile updates',
+                'bound': 'VALU issue of the rotation sets (one wave per SIMD and pair problem; the chain of a set runs through the '
+                         'pivot wave) + fp32-MFMA tile updates',
                 'note': 'batched two-sided block Jacobi on the %d-level covariances (C = 512, 512, 256, 128, 64; content and style); '
-                        'look-ahead launches {pair problems of step s, tile update of step s-1}, V resident in registers per '
-                        'launch segment from 24 matrices per solve on, second-order completion of the spectral functions; second-largest time class' % len(LEVELS)}
+                        'look-ahead launches {pair problems of step s, tile update of step s-1}; from 256 channels on the 64 x 64 pair '
+                        'problems are resident in REGISTERS (256 threads, 1 x W strips of cells, rim exchange through LDS; round 4); V '
+                        'resident in registers per launch segment from 24 matrices per solve on; second-order completion of the '
+                        'spectral functions; second-largest time class' % len(LEVELS)}
             line['breakdown_ms_per_step'] = {k: v['ms'] / args.steps for k, v in prof.items()}
         if world == 1 and not args.no_latency and not args.shared_style:
             line.update(latency_leg(ctx, S, args.alpha))
