@@ -98,7 +98,15 @@ struct Solver {
     for (int i = 0; i < C; ++i) V[(size_t)i * C + i] = 1.f;
     memset(&st, 0, sizeof(st));
     st.floor = 0.f; st.seg_stop = 0x7fffffff;
-    lds.assign(40000, 0.f);
+  }
+  // a block runs inside exactly the dynamic LDS its launch would get, guard words behind it
+  static constexpr int GUARD = 4096;
+  void arm(size_t bytes) {
+    lds.assign(bytes / 4 + GUARD, __builtin_nanf(""));                 // LDS is not initialised on the device either
+    for (int i = 0; i < GUARD; ++i) lds[bytes / 4 + i] = -12345.f;
+  }
+  void guard_ok(size_t bytes, const char* what) {
+    for (int i = 0; i < GUARD; ++i) if (lds[bytes / 4 + i] != -12345.f) { printf("LDS overrun in %s: float %d behind %zu bytes\n", what, i, bytes); exit(2); }
   }
   JacobiFusedArgs args(int cur, int par, int lg_u, int lg_d, int step_d, int step_u, bool has_d, bool has_u, bool first, bool with_v) {
     JacobiFusedArgs a;
@@ -110,16 +118,20 @@ struct Solver {
     return a;
   }
   void run_d(const JacobiFusedArgs& a) {
+    const size_t bytes = r4::lds_bytes<M2, EMUL_VAR>(1, 0, a.first, a.step_d);
     for (int g = 0; g < npair; ++g) {
-      std::fill(lds.begin(), lds.end(), __builtin_nanf(""));          // LDS is not initialised on the device either
+      arm(bytes);
       emul::run_block(r4::Lay<EMUL_VAR>::NTD, g, [&](int) { r4::fused_d<M2, EMUL_VAR>(a, 0, g, lds.data()); });
+      guard_ok(bytes, "fused_d");
     }
   }
   void run_u(const JacobiFusedArgs& a, bool with_v) {
     const int ntask = npair * (npair - 1) / 2 + npair + (with_v ? npair * npair : 0);
+    const size_t bytes = r4::lds_bytes<M2, EMUL_VAR>(0, 1, 0, 0);
     for (int task = 0; task < ntask; ++task) {
-      std::fill(lds.begin(), lds.end(), __builtin_nanf(""));
+      arm(bytes);
       emul::run_block(r4::NT, task, [&](int) { r4::fused_u<M2>(a, 0, task, lds.data()); });
+      guard_ok(bytes, "fused_u");
     }
   }
 };

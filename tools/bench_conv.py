@@ -10,6 +10,8 @@ SHAPES = [(64, 64, 512, 0, 5), (64, 64, 512, 1, 5), (64, 128, 256, 0, 5), (128, 
           (128, 64, 256, 0, 4), (128, 256, 128, 0, 4), (256, 256, 128, 0, 9), (256, 256, 128, 1, 6), (256, 128, 128, 0, 3),
           (256, 512, 64, 0, 3), (512, 512, 64, 0, 6), (512, 512, 64, 1, 3), (512, 256, 64, 0, 2), (512, 512, 32, 0, 3)]
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if len(sys.argv) > 2:                      # only the layers whose narrower side has at most this many channels
+    SHAPES = [s for s in SHAPES if min(s[0], s[1]) <= int(sys.argv[2])]
 ctx = Context(0)
 rng = np.random.default_rng(0)
 tot_ms = tot_fl = 0

@@ -314,9 +314,10 @@ template <> struct Lay<0> {
   static constexpr int NS = 8, NTD = 256;
   __device__ static constexpr int w(int sg) { return sg < 2 ? 1 : 5; }
   __device__ static constexpr int d0(int sg) { return sg < 2 ? sg : 2 + 5 * (sg - 2); }
-  // one exchange buffer: QQ4 f32x4[256] (qq of columns 0..3) | QP4 f32x4[256] (qp 0..3) | PQ f32x2[256] ({pq, Qpq} of column
-  // 0) | E[3][256] floats (qq of column 4, qp of the LAST column, Qqq of column 0)
-  static constexpr int QQ4 = 0, QP4 = 4096, PQ = 8192, E = 10240, BUF = 13312;
+  // one exchange buffer: QQ4 f32x4[192] (qq of columns 0..3 of the W = 5 lanes, index t - 64) | QP4 f32x4[192] (qp 0..3) |
+  // PQ f32x2[256] ({pq, Qpq} of column 0) | E[3][256] floats (qq of the LAST column, qp of the LAST column, Qqq of column 0).
+  // 11 KB a buffer: S image + two buffers + (c, s) = 38.8 KB, so that FOUR blocks of a {D, U} launch share a CU's 160 KB.
+  static constexpr int QQ4 = 0, QP4 = 3072, PQ = 6144, E = 8192, BUF = 11264;
 };
 template <> struct Lay<1> {
   static constexpr int NS = 16, NTD = 512;
@@ -337,6 +338,27 @@ template <int LAY> struct Xchg {
 // (per set on one wave they cost that wave ~310 cycles of every set: three transcendentals and their selects --
 // profiles/r04_jacobi_ts.txt -- and made it the pole of the block).
 constexpr int SX_LOG_B = 32 * 32 * 16;
+
+// dynamic LDS of one launch of the 256-thread kernel (every block of a launch gets the same amount: the larger of its D and
+// U parts).  Kept beside the device code because the CPU emulation (tests/emul) runs the blocks inside EXACTLY this many
+// bytes, guard words behind them.
+template <int M2, int LAY>
+constexpr size_t lds_bytes(int has_d, int has_u, int first, int step_d) {
+  constexpr size_t B = M2 / 2, F = sizeof(float);
+  size_t need = 0;
+  if (has_d) {
+    if (step_d < 0) need = 2 * M2 * (M2 + 1) * 2 * F + 4 * M2 * F;                     // intra sets: two {S, Q} images, D, O, dummy
+    else {
+      need = M2 * M2 * F + Xchg<LAY>::BYTES;                                           // S image, exchange area
+      if (need < 2 * M2 * M2 * F) need = 2 * M2 * M2 * F;                              // S and Q images of the epilogue
+      const size_t stage = (M2 * (M2 + 1) + 2 * M2 * (B + 1)) * F;                     // look-ahead: X (then W), Q1, Q2
+      if (!first && need < stage) need = stage;
+    }
+  }
+  const size_t u = 2 * M2 * (M2 + 1) * F;                                              // tile, one rotation matrix
+  if (has_u && need < u) need = u;
+  return need;
+}
 
 template <int W> struct Strip { f32x2 Xpp[W], Xpq[W], Xqp[W], Xqq[W]; };    // {S, Q} pairs; Xpq / Xqq are PHYSICAL slots
 
@@ -391,8 +413,8 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
     const unsigned char* b = xb + (S & 1) * SX_BUF;
     if constexpr (LAY == 0) {
       if constexpr (W == 5) {
-        const f32x4 q4 = *reinterpret_cast<const f32x4*>(b + L::QQ4 + dn * 16);
-        const f32x4 p4 = *reinterpret_cast<const f32x4*>(b + L::QP4 + dn * 16);
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(b + L::QQ4 + (dn - 64) * 16);
+        const f32x4 p4 = *reinterpret_cast<const f32x4*>(b + L::QP4 + (dn - 64) * 16);
         const float q5 = *reinterpret_cast<const float*>(b + L::E + dn * 4);
         const float pl = *reinterpret_cast<const float*>(b + L::E + 1024 + dl * 4);
         static_for<W>([&](auto J) {
@@ -401,7 +423,7 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
           R.Xqp[j][0] = j == 0 ? pl : p4[j > 0 ? j - 1 : 0];
         });
       } else {
-        R.Xqq[0][0] = *reinterpret_cast<const float*>(b + L::QQ4 + dn * 16);
+        R.Xqq[0][0] = *reinterpret_cast<const float*>(b + L::E + dn * 4);
         R.Xqp[0][0] = *reinterpret_cast<const float*>(b + L::E + 1024 + dl * 4);
       }
       R.Xpq[LASTP] = *reinterpret_cast<const f32x2*>(b + L::PQ + rt * 8);
@@ -479,12 +501,10 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
     unsigned char* b = xb + NX * SX_BUF;
     if constexpr (LAY == 0) {
       if constexpr (W == 5) {
-        *reinterpret_cast<f32x4*>(b + L::QQ4 + t * 16) = f32x4{nqq[0], nqq[1], nqq[2], nqq[3]};
-        *reinterpret_cast<f32x4*>(b + L::QP4 + t * 16) = f32x4{nqp[0], nqp[1], nqp[2], nqp[3]};
-        *reinterpret_cast<float*>(b + L::E + t * 4) = nqq[4];
-      } else {
-        *reinterpret_cast<float*>(b + L::QQ4 + t * 16) = nqq[0];
+        *reinterpret_cast<f32x4*>(b + L::QQ4 + (t - 64) * 16) = f32x4{nqq[0], nqq[1], nqq[2], nqq[3]};
+        *reinterpret_cast<f32x4*>(b + L::QP4 + (t - 64) * 16) = f32x4{nqp[0], nqp[1], nqp[2], nqp[3]};
       }
+      *reinterpret_cast<float*>(b + L::E + t * 4) = nqq[W - 1];
       *reinterpret_cast<float*>(b + L::E + 1024 + t * 4) = nqp[W - 1];
       *reinterpret_cast<f32x2*>(b + L::PQ + t * 8) = R.Xpq[P0];
       *reinterpret_cast<float*>(b + L::E + 2048 + t * 4) = R.Xqq[P0][1];
@@ -606,7 +626,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     float* Xs = jsm;                                // [M2][M2 + 1]  tile (g1, g2) of the state before U(step_u)
     float* Q1s = Xs + M2 * (M2 + 1);                // [M2][B + 1]   columns h1 of Q_g1
     float* Q2s = Q1s + M2 * (B + 1);                // [M2][B + 1]   columns h2 of Q_g2
-    float* Ws = Q2s + M2 * (B + 1);                 // [B][M2 + 1]   Q_g1[:, h1]^T X
+    float* Ws = Xs;                                 // [B][M2 + 1]   Q_g1[:, h1]^T X -- over X, once every wave is done with X
     constexpr int NV = FR / 4 / NT;                 // float4 per thread of a 64 x 64 tile
     f32x4 xv[NV], qv[NV];
     float* Qdst[NV];
@@ -645,15 +665,23 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
         for (int j = 0; j < 4; ++j) { Xs[xr[i] * (M2 + 1) + xc[i] + j] = xv[i][j]; Qdst[i][j * (B + 1)] = qv[i][j]; }
       __syncthreads();
       JTS(2);
+      constexpr int NJ = (B / 16) * NW / NWAVES;                        // W = Q_g1[:, h1]^T X   (B x M2): 8 tiles over the waves
+      f32x4 wacc[NJ];
 #pragma unroll
-      for (int jb = 0; jb < (B / 16) * NW / NWAVES; ++jb) {             // W = Q_g1[:, h1]^T X   (B x M2): 8 tiles over the waves
-        const int job = wave * ((B / 16) * NW / NWAVES) + jb, tr = job / NW, tj = job % NW;
+      for (int jb = 0; jb < NJ; ++jb) {
+        const int job = wave * NJ + jb, tr = job / NW, tj = job % NW;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int kk = 0; kk < M2; kk += 4)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Q1s[(kk + lq) * (B + 1) + 16 * tr + li], Xs[(kk + lq) * (M2 + 1) + 16 * tj + li], acc, 0, 0, 0);
+        wacc[jb] = acc;
+      }
+      __syncthreads();                              // X has been read by every wave: W takes its place
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ws[(16 * tr + 4 * lq + r) * (M2 + 1) + 16 * tj + li] = acc[r];
+      for (int jb = 0; jb < NJ; ++jb) {
+        const int job = wave * NJ + jb, tr = job / NW, tj = job % NW;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ws[(16 * tr + 4 * lq + r) * (M2 + 1) + 16 * tj + li] = wacc[jb][r];
       }
       __syncthreads();
       if (wave < (B / 16) * (B / 16)) {                                 // crit = W Q_g2[:, h2]   (B x B): one tile per wave
@@ -794,20 +822,24 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
   int hi, hj, gi = 0, gj = 0;
   block_pair(h, p.step_u, nblk, hi, hj);
   if (!is_v) block_pair(g, p.step_u, nblk, gi, gj);
+  // LDS: the tile and ONE rotation matrix (33 KB: with the 39 KB of a pair problem four blocks of a {D, U} launch fit a
+  // CU); Q_g waits in registers and replaces Q_h in LDS when T replaces X
   float* Xs = jsm;
-  float* Qhs = Xs + M2 * PITCH;
-  float* Qgs = Qhs + M2 * PITCH;
+  float* Qs = Xs + M2 * PITCH;
+  f32x4 gv[NV];
   {
     const float* X = is_v ? p.V + m * cc : p.Pr + m * cc;
-    f32x4 xv[NV], hv[NV], gv[NV];
+    f32x4 xv[NV], hv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + i * NT, e4 = f * 4, lr = e4 / M2, lc = e4 % M2;
       const int gr = is_v ? g * M2 + lr : pair_index<B>(lr, gi, gj);
       xv[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * C + pair_index<B>(lc, hi, hj));
-      hv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + h) * FR + e4);
-      gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!is_v) gv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + g) * FR + e4);
+      hv[i] = gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!is_v) {                                  // (a V task takes Q_h as fp16 fragments straight from the log)
+        hv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + h) * FR + e4);
+        gv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + g) * FR + e4);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -817,8 +849,7 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         Xs[lr * PITCH + lc + j] = xv[i][j];
-        Qhs[(qr + j) * PITCH + qc] = hv[i][j];
-        if (!is_v) Qgs[(qr + j) * PITCH + qc] = gv[i][j];
+        if (!is_v) Qs[(qr + j) * PITCH + qc] = hv[i][j];
       }
     }
   }
@@ -857,7 +888,7 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
     const float a = Xs[(16 * ti + li) * PITCH + kk + lq];
 #pragma unroll
     for (int tj = 0; tj < NW; ++tj)
-      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Qhs[(kk + lq) * PITCH + 16 * tj + li], acc[tj], 0, 0, 0);
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Qs[(kk + lq) * PITCH + 16 * tj + li], acc[tj], 0, 0, 0);
   }
   __syncthreads();
 #pragma unroll
@@ -866,10 +897,17 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
     for (int r = 0; r < 4; ++r) Xs[(16 * ti + 4 * lq + r) * PITCH + 16 * tj + li] = acc[tj][r];
     acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int qr, qc;
+    qfrag_rc<M2>(tid + i * NT, qr, qc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Qs[(qr + j) * PITCH + qc] = gv[i][j];
+  }
   __syncthreads();
 #pragma unroll 2
   for (int kk = 0; kk < M2; kk += 4) {      // Y = Qg^T T
-    const float a = Qgs[(kk + lq) * PITCH + 16 * ti + li];
+    const float a = Qs[(kk + lq) * PITCH + 16 * ti + li];
 #pragma unroll
     for (int tj = 0; tj < NW; ++tj)
       acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[(kk + lq) * PITCH + 16 * tj + li], acc[tj], 0, 0, 0);

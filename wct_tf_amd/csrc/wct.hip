@@ -992,25 +992,15 @@ __global__ __launch_bounds__((M2 / 2) * (M2 / 2), M2 == 64 ? 8 : 2) void jacobi_
 namespace r4 {
 template <int M2, int LAY>
 static size_t fused_lds(int has_d, int has_u, int first, int step_d) {
-  constexpr int B = M2 / 2;
-  size_t need = 0;
-  if (has_d) {
-    if (step_d < 0) need = jacobi_diag_lds<M2>(-1, true);                               // intra sets: two {S, Q} images
-    else {
-      need = (size_t)M2 * M2 * sizeof(float) + Xchg<LAY>::BYTES;                       // S image, exchange area
-      need = std::max(need, (size_t)2 * M2 * M2 * sizeof(float));                       // S and Q images of the epilogue
-      if (!first) need = std::max(need, (size_t)(M2 * (M2 + 1) + 2 * M2 * (B + 1) + B * (M2 + 1)) * sizeof(float));
-    }
-  }
-  if (has_u) need = std::max(need, (size_t)3 * M2 * (M2 + 1) * sizeof(float));
-  return need;
+  static_assert(lds_bytes<64, 0>(1, 1, 0, 0) * 4 <= 160 * 1024, "four blocks of a {D, U} launch per CU");
+  return lds_bytes<M2, LAY>(has_d, has_u, first, step_d);
 }
 }  // namespace r4
 
 
 // grid: [nmat * npair pair problems (if has_d)] [ntask * nmat update tasks, task-major (if has_u)]; 256 threads
 template <int M2, int LAY>
-__global__ __launch_bounds__(r4::Lay<LAY>::NTD, LAY ? 4 : 3) void jacobi_fused4_kernel(JacobiFusedArgs p) {
+__global__ __launch_bounds__(r4::Lay<LAY>::NTD, 4) void jacobi_fused4_kernel(JacobiFusedArgs p) {
   extern __shared__ __attribute__((aligned(16))) float jsm[];
   constexpr int B = M2 / 2;
   const int npair = p.C / B / 2;
