@@ -841,3 +841,47 @@ def test_epilogue_statistics_equal_the_pass_over_the_features(ctx, weights, tmp_
     assert np.array_equal(got_wct, ref['a'])
     assert np.array_equal(got_adain, ref['b'])
     assert len({f.tobytes() for f in got_wct}) == 3
+
+
+def test_conv1_1_inside_conv1_2s_patch_loader_gives_the_bits_of_the_two_launches(ctx, weights, tmp_path):
+    """Encoder passes whose relu1_1 feeds nothing but conv1_2 (every content pass of a level >= 2) compute conv1_1 inside
+    conv1_2's patch loader (ConvArgs::img1, csrc/conv.hip: the 64-channel full-resolution map is never written).  The features
+    and the frames must be the ones of the two-launch path (WCT_FUSE_CONV1=0, read once per process: a subprocess), bit for
+    bit: full tiles, ragged tiles in both directions, images smaller than a tile, the reflected borders, a batch."""
+    import subprocess, sys
+    rng = np.random.default_rng(11)
+    sizes = [(512, 512), (70, 100), (33, 17), (5, 7), (160, 224), (64, 48)]
+    imgs = {('i%d' % i): rng.random((h, w, 3), dtype=np.float32) * 1.2 - 0.1 for i, (h, w) in enumerate(sizes)}
+    cs = rng.integers(0, 256, (3, 96, 80, 3), dtype=np.uint8)
+    st = rng.integers(0, 256, (72, 64, 3), dtype=np.uint8)
+    np.savez(tmp_path / 'in.npz', cs=cs, st=st, **imgs)
+    body = (
+        "d = np.load(IN)\n"
+        "c = Context(0); c.set_weights(synthetic_weights(seed=42))\n"
+        "out = {}\n"
+        "for k in sorted(k for k in d.files if k.startswith('i')):\n"
+        "    for lv in ('relu2_1', 'relu3_1'):\n"
+        "        if min(d[k].shape[:2]) >= 5 or lv == 'relu2_1':\n"
+        "            out[k + lv] = c.encode(d[k], lv)\n"
+        "out['frames'] = c.stylize_batch(d['cs'], d['st'], RELU_TARGETS, alpha=0.8)\n")
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from wct_tf_amd.context import Context\n"
+        "from wct_tf_amd.weights import synthetic_weights, RELU_TARGETS\n"
+        "IN = %r\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / 'in.npz'))
+        + body + "np.savez(%r, **out)\n" % str(tmp_path / 'out.npz'))
+    env = dict(os.environ, WCT_FUSE_CONV1='0')
+    subprocess.run([sys.executable, '-c', script], check=True, env=env, timeout=600)
+    ref = np.load(tmp_path / 'out.npz')
+    n = 0
+    for k in sorted(imgs):
+        for lv in ('relu2_1', 'relu3_1'):
+            if k + lv in ref.files:
+                got = ctx.encode(imgs[k], lv)
+                assert got.shape == ref[k + lv].shape
+                assert np.array_equal(got, ref[k + lv]), (k, lv, float(np.abs(got - ref[k + lv]).max()))
+                assert np.abs(got).max() > 0
+                n += 1
+    assert n >= 11
+    assert np.array_equal(ctx.stylize_batch(cs, st, RELU_TARGETS, alpha=0.8), ref['frames'])

@@ -523,7 +523,12 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
   TRY(ensure(c, c->act[1], act_bytes));
   half_t* cur = (half_t*)c->act[0].p;
   half_t* nxt = (half_t*)c->act[1].p;
-  {
+  // relu1_1 is read by conv1_2 only (no tap on it: every content pass of a level >= 2): conv1_1 moves into conv1_2's patch
+  // loader (ConvArgs::img1) -- the 64-channel full-resolution map is neither written nor read, and the bits are the same.
+  // (WCT_FUSE_CONV1=0: the two launches; test hook, read once per process)
+  static const int fuse_conv1_env = getenv("WCT_FUSE_CONV1") ? atoi(getenv("WCT_FUSE_CONV1")) : 1;
+  const bool fuse_conv1 = fuse_conv1_env && deepest > 1 && !taps32[1];
+  if (!fuse_conv1) {
     ConvFirstArgs a;
     a.x = img; a.wfrag = c->first_w; a.bias = c->first_b;
     a.y16 = deepest > 1 ? cur : nullptr; a.y32 = taps32[1];
@@ -547,6 +552,15 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
     const bool last = tap == deepest;
     const bool fuse = pool_after[i] && fuse_pool;
     float* const us = tap && taps32[tap] && usum ? usum[tap] : nullptr;
+    if (i == 0 && fuse_conv1) {
+      ConvArgs a;
+      a.x = nullptr; a.w = l.w; a.bias = l.b; a.y16 = nxt; a.y32 = nullptr; a.usum = nullptr; a.umax = nullptr;
+      a.B = B; a.H = h; a.W = w; a.Cin = 64; a.Cout = 64; a.upsample = 0; a.relu = 1; a.pool = fuse;
+      a.img1 = img; a.w1frag = c->first_w; a.bias1 = c->first_b; a.clamp01 = clamp01;
+      const double px = (double)B * h * w, out_px = fuse ? (double)B * ((h + 1) / 2) * ((w + 1) / 2) : px;
+      ProfScope ps(c, 0, 2.0 * px * (27 * 64 + 9 * 64 * 64), px * 12 + out_px * 64 * 2 + 9.0 * 64 * 64 * 2);
+      TRY(launch_conv3x3(a, c->stream));
+    } else
     TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1, fuse, us, us ? umax[tap] : nullptr));
     half_t* t = cur; cur = nxt; nxt = t;
     if (last) break;

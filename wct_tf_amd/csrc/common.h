@@ -73,6 +73,13 @@ struct ConvArgs {
   // atomicMax: zero it before the launch
   float* usum;
   unsigned* umax;
+  // conv1_1 fused into the patch loader (conv1_2 of an encoder pass whose relu1_1 nobody else reads; Cin = Cout = 64): the
+  // block computes its halo patch of relu1_1 activations from the IMAGE instead of reading them -- x is unused, img1 is the
+  // [B][H][W][3] fp32 image and (w1frag, bias1, clamp01) are conv1_1's ConvFirstArgs.  null img1: off.
+  const float* img1 = nullptr;
+  const half_t* w1frag = nullptr;
+  const float* bias1 = nullptr;
+  int clamp01 = 0;
 };
 // The maxima of an image are merged into UMAX_SLOTS words (two cache lines) instead of one: tens of thousands of
 // wavefronts bumping ONE word -- or 32 words of one cache line -- serialise in a single L2 channel (measured: +94 us per

@@ -23,7 +23,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // boundaries; the launcher prints the per-launch means.  Compiled out of the product.
 #ifdef CONV_TS
 __device__ unsigned long long conv_ts[16384 * 10];
-#define TS(slot) do { if (threadIdx.x == 0) { const unsigned fl_ = blockIdx.x + gridDim.x * blockIdx.y; if (fl_ < 16384) conv_ts[fl_ * 10 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define TS(slot) do { if (ts_on && threadIdx.x == 0) { const unsigned fl_ = blockIdx.x + gridDim.x * blockIdx.y; if (fl_ < 16384) conv_ts[fl_ * 10 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define TS(slot) do {} while (0)
 #endif
@@ -123,17 +123,19 @@ __device__ __forceinline__ void conv_epilogue_t(const ConvArgs& p, f32x16 (&acc)
           hi = __builtin_elementwise_max(hi, lo2);
         }
         if (POOL) {
-          // column pair by DPP quad_perm(1,0,3,2), row pair by ds_swizzle xor 16
+          // column pair by DPP quad_perm(1,0,3,2); row pair (lane ^ 16) by v_permlane16_swap of the value with itself: one
+          // result holds the even row in both rows of lanes, the other the odd row -- their max is the pair's in every lane.
+          // (was ds_swizzle xor 16: an LDS round trip per value, 64 of them in a row per wave)
           const h2 zero = {(half_t)0.f, (half_t)0.f};
           h2 q[2] = {in_img ? lo : zero, in_img ? hi : zero};
 #pragma unroll
           for (int d = 0; d < 2; ++d) {
-            int t = __builtin_bit_cast(int, q[d]);
-            h2 o = __builtin_bit_cast(h2, __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true));
+            unsigned t = __builtin_bit_cast(unsigned, q[d]);
+            const h2 o = __builtin_bit_cast(h2, __builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xF, 0xF, true));
             q[d] = __builtin_elementwise_max(q[d], o);
-            t = __builtin_bit_cast(int, q[d]);
-            o = __builtin_bit_cast(h2, __builtin_amdgcn_ds_swizzle(t, 0x401F));
-            q[d] = __builtin_elementwise_max(q[d], o);
+            t = __builtin_bit_cast(unsigned, q[d]);
+            const auto rows = __builtin_amdgcn_permlane16_swap(t, t, false, false);
+            q[d] = __builtin_elementwise_max(__builtin_bit_cast(h2, (unsigned)rows[0]), __builtin_bit_cast(h2, (unsigned)rows[1]));
           }
           lo = q[0]; hi = q[1];
         }
@@ -178,8 +180,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[N
 //    771 TFLOP/s over the layer mix vs 943 for this one.)
 //  * __launch_bounds__(256, 2): two blocks resident per CU cover each other's chunk boundaries.
 // ---------------------------------------------------------------------------
-template <int TH, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles) {
+template <int TH, int BN, int WM, int WN, bool FUSE1 = false>
+__global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles, int strip) {
   constexpr int PH = TH + 2;
   constexpr int MT = (TH / 2) / WM;
   constexpr int NT = (BN / 32) / WN;
@@ -193,6 +195,17 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   constexpr int DUMP_OFF = PATCH_BYTES;          // a buffer = patch + the dump slots of the idle loader lanes
   constexpr int BUF_STRIDE = PATCH_BYTES + 4096;
   constexpr int BIAS_OFF = NBUF * BUF_STRIDE;
+  // FUSE1 (see the comment above make_patch below): the image patch behind the bias -- (TH + 4) x 20 pixels x 3 floats, row ry
+  // = image row reflect(y0 - 2 + ry), then 4 zero floats (the target of the padded k = 27..31)
+  // -- every image value as the packed pair {fp16 hi, fp16 lo} of conv_first_kernel's split; 16 zero words behind it (the reads
+  // of the padded k = 27..31 may run that far); conv1_1's weight fragments (8 KB) and bias
+  constexpr int IMG_OFF = BIAS_OFF + BN * 4, IMG_H = TH + 4, IMG_W = 20, IMG_ROW = IMG_W * 3, IMG_ZERO = IMG_OFF + IMG_H * IMG_ROW * 4;
+  constexpr int W1_OFF = IMG_ZERO + 64, B1_OFF = W1_OFF + 8192;
+  // -- and the landing area of the NEXT tile's image patch (global -> LDS directly, no registers: 9 dwords per thread, planar
+  // [pixel slot i][channel][thread] because the hardware writes lane l of a wave at base + 4 l; the 12-byte form of the
+  // instruction did not land the pixels at base + 12 l -- parity test red -- and was worth 2.5 % of this kernel)
+  constexpr int STG_OFF = B1_OFF + 256;
+  static_assert(!FUSE1 || (BN == 64 && !(((TH / 2) / WM) * ((BN / 32) / WN) > 8)), "FUSE1: 64 output channels, single patch buffer");
   // tap at which the next K-chunk's patch loads are issued (their registers are live from there to the
   // chunk boundary only); the tall tile has no registers to spare and loads at the boundary
   constexpr int PF_TAP = TH <= 16 ? 6 : 9;
@@ -200,20 +213,34 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const patch_lds = smem;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  [[maybe_unused]] bool ts_on = true;          // (-DCONV_TS) a strip block stamps its SECOND tile: entry = the end of the first
   TS(8);
-
   int bid = blockIdx.x;
   const int ntile = bid % n_tiles;
   bid /= n_tiles;
-  const int tx = bid % tiles_x;
-  const int ty = bid / tiles_x;
+  // FUSE1: a block walks a strip of `strip` horizontally adjacent tiles (the next tile's image patch is fetched under the
+  // epilogue of the current one); blockIdx.x counts strips
+  const int strips_x = FUSE1 ? (tiles_x + strip - 1) / strip : tiles_x;
+  const int tx = FUSE1 ? (bid % strips_x) * strip : bid % strips_x;
+  const int ty = bid / strips_x;
   const int b = blockIdx.y;
-  const int y0 = ty * TH, x0 = tx * TW;
+  int y0 = ty * TH;
+  int x0 = tx * TW;
+  int strip_i = 0;
   const int n0 = ntile * BN;
+  int tid_ = threadIdx.x;
+
+next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
+  // (thread index and tile row are made opaque per iteration: hoisted out of the strip loop, everything that depends on the lane
+  //  and y0 only -- fragment addresses, reflected rows, patch and store offsets -- stayed live across the tile's epilogue and
+  //  27 registers were spilled; recomputing them costs a few dozen instructions per tile)
+  if (FUSE1) asm volatile("" : "+v"(tid_), "+s"(y0));
+  ts_on = !FUSE1 || strip < 2 || strip_i == 1;
+  if (FUSE1 && strip >= 2) TS(8);
+  const int tid = tid_;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int Hin = p.upsample ? p.H / 2 : p.H;
   const int Win = p.upsample ? p.W / 2 : p.W;
@@ -262,14 +289,8 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7FFFFFFF, 0x00020000);
 
   f32x16 acc[NT][MT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
   // the block's bias values -> LDS (read back by the epilogue; visible after the first patch barrier)
-  if (tid < BN / 4)
+  if (tid < BN / 4 && strip_i == 0)
     *reinterpret_cast<f32x4*>(smem + BIAS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias + n0 + tid * 4);
 
   const int n_chunks = p.Cin / BK;           // even: Cin is a multiple of 64 on this path
@@ -300,14 +321,157 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
       *reinterpret_cast<u32x4*>(smem + patch_dst[i] + buf * BUF_STRIDE) = patch_regs[i];
   };
 
+  // FUSE1: the K-chunk's patch is COMPUTED -- relu1_1 = ReLU(conv1_1(image)) at the patch's (reflected) positions, channels
+  // 32 chunk .. + 31 -- with conv_first_kernel's arithmetic (split fp16 operands, k = ky * 9 + kx * 3 + c, the three MFMAs per
+  // k-step in its order, bias added last, one rounding to fp16; the ReLU on the rounded pair, which is the same value): bit for
+  // bit what conv_first_kernel would have stored and the loader read back.
+  //  * pixel tiles (32 MFMA columns) without a division: PH / 2 "main" tiles = patch rows (2m, 2m + 1) x columns 0..15, and
+  //    ceil(PH / 16) "edge" tiles = 16 rows x columns 16, 17; tile T = 4 t + wave.
+  //  * the activation of patch pixel (py, px) is the one at (ay, ax) = (reflect(y0 - 1 + py), reflect(x0 - 1 + px)); its 27
+  //    inputs are three runs of 9 words in the image patch: rows ay - y0 + 1 + ky, from column 3 (ax - x0 + 1).
+  //  * a lane needs the 8 values k = 16 ks + 8 kgrp + j.  For kgrp = 0 these sit at the word offsets j | R+7, R+8, 2R .. 2R+5
+  //    (R = IMG_ROW); for kgrp = 1 at the SAME offsets plus 8 (j = 0 of ks 0; j = 2 of ks 1) or plus R - 1 (the others) -- so
+  //    two per-lane bases and immediate offsets, no address arithmetic per read.  (k = 27..31, kgrp 1: the weights are 0, the
+  //    reads land on finite neighbours or on the zero words.)
+  auto make_patch = [&](int chunk) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const unsigned char* w1 = smem + W1_OFF + chunk * 4096;
+    half8 wh[2], wl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      wh[ks] = *reinterpret_cast<const half8*>(w1 + ((ks * 2 + 0) * 64 + lane) * 16);
+      wl[ks] = *reinterpret_cast<const half8*>(w1 + ((ks * 2 + 1) * 64 + lane) * 16);
+    }
+    const int l = lane & 31, kg = lane >> 5;
+    f32x4 b1[4];
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) b1[rq] = *reinterpret_cast<const f32x4*>(smem + B1_OFF + (chunk * 32 + 8 * rq + 4 * kg) * 4);
+    constexpr int NMAIN = PH / 2, NEDGE = (PH + 15) / 16, NT1 = (NMAIN + NEDGE + 3) / 4, R = IMG_ROW;
+    const int pxm = l & 15, pxe = 16 + (l & 1);
+    const int colm = IMG_OFF + (reflect_idx(x0 - 1 + pxm, p.W) - x0 + 1) * 12 - (y0 - 1) * R * 4;
+    const int cole = IMG_OFF + (reflect_idx(x0 - 1 + pxe, p.W) - x0 + 1) * 12 - (y0 - 1) * R * 4;
+    const int dstm = pxm * 64 + kg * 8, dste = pxe * 64 + kg * 8, swm = (pxm >> 2) & 3;     // (columns 16, 17: swizzle 0)
+#pragma unroll 1                     // (unrolled twice the kernel spills 30 registers)
+    for (int t = 0; t < NT1; ++t) {
+      const int T = t * 4 + wave;                                  // wave-uniform
+      const bool edge = T >= NMAIN;
+      const int py = edge ? (T - NMAIN) * 16 + (l >> 1) : 2 * T + (l >> 4);
+      const bool valid = py < PH && T < NMAIN + NEDGE;
+      const int pyc = py < PH ? py : PH - 1;
+      const int base = (edge ? cole : colm) + reflect_idx(y0 - 1 + pyc, p.H) * (R * 4);
+      const unsigned char* b8 = smem + base + kg * 32;
+      const unsigned char* bR = smem + base + kg * (R - 1) * 4;
+      unsigned w[2][8];
+      w[0][0] = *reinterpret_cast<const unsigned*>(b8);
+#pragma unroll
+      for (int j = 1; j < 8; ++j) w[0][j] = *reinterpret_cast<const unsigned*>(bR + j * 4);
+      w[1][0] = *reinterpret_cast<const unsigned*>(bR + (R + 7) * 4);
+      w[1][1] = *reinterpret_cast<const unsigned*>(bR + (R + 8) * 4);
+#pragma unroll
+      for (int j = 2; j < 8; ++j) w[1][j] = *reinterpret_cast<const unsigned*>(b8 + (2 * R + j - 2) * 4);
+      f32x16 a1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned uh[4], ul[4];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          uh[i2] = __builtin_amdgcn_perm(w[ks][2 * i2 + 1], w[ks][2 * i2], 0x05040100u);   // the two hi halves
+          ul[i2] = __builtin_amdgcn_perm(w[ks][2 * i2 + 1], w[ks][2 * i2], 0x07060302u);   // the two lo halves
+        }
+        const half8 bh = __builtin_bit_cast(half8, u32x4{uh[0], uh[1], uh[2], uh[3]});
+        const half8 bl = __builtin_bit_cast(half8, u32x4{ul[0], ul[1], ul[2], ul[3]});
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], bh, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bl, a1, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], bh, a1, 0, 0, 0);
+      }
+      // the lane holds channels 8 rq + 4 kgrp .. + 3 of its pixel: half of the 16-byte piece rq
+      const int dst = valid ? pyc * (PITCH * 64) + (edge ? dste : dstm) : DUMP_OFF + tid * 16;
+      const int sw = valid && !edge ? swm : 0;
+      const h2v zero2 = {(half_t)0.f, (half_t)0.f};
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        h2v h0 = {(half_t)(a1[rq * 4 + 0] + b1[rq][0]), (half_t)(a1[rq * 4 + 1] + b1[rq][1])};
+        h2v h1 = {(half_t)(a1[rq * 4 + 2] + b1[rq][2]), (half_t)(a1[rq * 4 + 3] + b1[rq][3])};
+        h0 = __builtin_elementwise_max(h0, zero2);
+        h1 = __builtin_elementwise_max(h1, zero2);
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<u32x2*>(smem + dst + (valid ? (rq ^ sw) * 16 : 0)) = u32x2{__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1)};
+      }
+    }
+  };
+
+  // FUSE1: image patch of the tile at xt -> landing area (asynchronous; vmcnt) / landing area -> image patch as split pairs
+  constexpr int IMG_NP = IMG_H * IMG_W, IMG_PER = (IMG_NP + 255) / 256;
+  auto fetch_img = [&](int xt) {
+    const float* ib = p.img1 + (size_t)b * p.H * p.W * 3;
+#pragma unroll
+    for (int i = 0; i < IMG_PER; ++i) {
+      const int e = tid + i * 256, ee = e < IMG_NP ? e : IMG_NP - 1;
+      const int ry = ee / IMG_W, rx = ee - ry * IMG_W;
+      const float* s = ib + ((size_t)reflect_idx(y0 - 2 + ry, p.H) * p.W + reflect_idx(xt - 2 + rx, p.W)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        __builtin_amdgcn_global_load_lds(s + c, reinterpret_cast<__attribute__((address_space(3))) void*>(
+            (__attribute__((address_space(3))) unsigned char*)smem + STG_OFF + ((i * 3 + c) * 256 + wave * 64) * 4), 4, 0, 0);
+    }
+  };
+  auto park_img = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's words have landed (nobody else reads them)
+#pragma unroll
+    for (int i = 0; i < IMG_PER; ++i) {
+      const int e = tid + i * 256;
+      if (e < IMG_NP) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float raw = *reinterpret_cast<const float*>(smem + STG_OFF + ((i * 3 + c) * 256 + tid) * 4);
+          const float v = p.clamp01 ? fminf(fmaxf(raw, 0.f), 1.f) : raw;
+          const half_t hi = (half_t)v, lo = (half_t)(v - (float)hi);
+          *reinterpret_cast<unsigned*>(smem + IMG_OFF + (e * 3 + c) * 4) =
+              (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+        }
+      }
+    }
+  };
+  if (FUSE1 && strip_i == 0) {
+    fetch_img(x0);
+    // conv1_1's weight fragments (8 KB = 256 x 32 B) and bias, once per block
+    const u32x4 wa = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1frag) + tid * 32);
+    const u32x4 wb = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(p.w1frag) + tid * 32 + 16);
+    *reinterpret_cast<u32x4*>(smem + W1_OFF + tid * 32) = wa;
+    *reinterpret_cast<u32x4*>(smem + W1_OFF + tid * 32 + 16) = wb;
+    if (tid < 16) {
+      *reinterpret_cast<f32x4*>(smem + B1_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias1 + tid * 4);
+      *reinterpret_cast<unsigned*>(smem + IMG_ZERO + tid * 4) = 0u;
+    }
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
   TS(1);
-  load_patch(0);
+  if (FUSE1) {
+    // (the image patch in LDS was last read by the previous tile's second make_patch, which ends in a barrier)
+    park_img();
+    TS(9);
+  } else {
+    load_patch(0);
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
       wf[0][nt][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wfrag[nt] + ks * 1024, 0, 0));
-  store_patch(0);
+  if (FUSE1) {
+    __syncthreads();
+    make_patch(0);
+  } else {
+    store_patch(0);
+  }
   __syncthreads();
   TS(2);
   read_group(bf[0], 0, 0, 0, 0);
@@ -332,7 +496,7 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
             wf[(t + 1) & 1][nt][ks] =
                 __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wfrag[nt] + ks * 1024, wtap, 0));
       }
-      if (tap == PF_TAP && more) load_patch(chunk_i + 1);
+      if (!FUSE1 && tap == PF_TAP && more) load_patch(chunk_i + 1);
       // 2) second k-step's pixels go out, first k-step's MFMAs run on fragments read during the previous tap
       read_group(bf[1], ky, kx, 1, buf);
       if (DB && tap == 8 && more) store_patch(buf ^ 1);
@@ -349,7 +513,12 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
         mma_group(wf[t & 1], bf[1], 1);
         if (more) {
           __syncthreads();
-          if (!DB) {
+          if (FUSE1) {
+            TS(3);
+            make_patch(chunk_i + 1);
+            __syncthreads();
+            TS(4);
+          } else if (!DB) {
             if (PF_TAP > 8) load_patch(chunk_i + 1);
             store_patch(0);
             __syncthreads();
@@ -361,23 +530,37 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
     }
   }
   TS(5);
+  const bool more_tiles = FUSE1 && strip_i + 1 < strip && tx + strip_i + 1 < tiles_x;      // uniform
+  if (more_tiles) fetch_img(x0 + TW);        // arrives under the epilogue (whose stores sit on the same in-order counter)
+  TS(0);
   conv_epilogue<MT, NT>(p, acc, b, y0, x0, n0, wm, wn, lane, smem + BIAS_OFF);
   TS(6);
+  if (more_tiles) {
+    TS(7);
+    ++strip_i;
+    x0 += TW;
+    goto next_tile;
+  }
 #ifdef CONV_TS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TS(7);
 #endif
 }
 
-template <int TH, int BN, int WM, int WN>
+template <int TH, int BN, int WM, int WN, bool FUSE1 = false>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
   const int n_tiles = a.Cout / BN;
   constexpr int PH = TH + 2;
   constexpr int NBUF = ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 2 : 1;
-  const size_t lds = (size_t)NBUF * (PH * PITCH * 64 + 4096) + BN * sizeof(float);     // NBUF x (patch, dump slots), bias
-  dim3 grid(tiles_x * tiles_y * n_tiles, a.B);
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
+  const size_t lds = (size_t)NBUF * (PH * PITCH * 64 + 4096) + BN * sizeof(float)      // NBUF x (patch, dump slots), bias
+                     + (FUSE1 ? (size_t)(TH + 4) * 20 * 3 * 4 + 64 + 8192 + 256 + 9 * 1024 : 0);  // image patch, zero words, conv1_1 weights and bias, landing area
+  // FUSE1: strips of 4 / 2 tiles per block while that leaves the chip >= 4 blocks per resident slot (512 slots)
+  const long tiles = (long)tiles_x * tiles_y * a.B;
+  static const int strip_force = tune_int("WCT_FUSE1_STRIP", 0);   // tuning switch
+  const int strip = !FUSE1 ? 1 : strip_force ? strip_force : tiles >= 8192 ? 4 : tiles >= 4096 ? 2 : 1;
+  dim3 grid((FUSE1 ? cdiv(tiles_x, strip) : tiles_x) * tiles_y * n_tiles, a.B);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles, strip);
 #ifdef CONV_TS
   if (a.B >= 8) {
     static int nlaunch = 0;
@@ -386,11 +569,18 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
     static unsigned long long host[16384 * 10];
     (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(conv_ts), sizeof(host));
     const int nb = (int)(grid.x * grid.y < 16384 ? grid.x * grid.y : 16384);
-    double sum[6] = {0};       // slots: 8 entry, 1 addresses ready, 2 first patch in LDS, 5 taps done, 6 epilogue issued, 7 stores drained
+    double sum[6] = {0}, mid = 0;   // slots: 8 entry, 1 addresses ready, 2 first patch in LDS, (FUSE1: 3-4 the second chunk's patch,) 5 taps done, 6 epilogue issued, 7 stores drained
     for (int i = 0; i < nb; ++i) {
       const unsigned long long* h = host + (size_t)i * 10;
       sum[0] += (double)(h[1] - h[8]); sum[1] += (double)(h[2] - h[1]); sum[2] += (double)(h[5] - h[2]);
       sum[3] += (double)(h[6] - h[5]); sum[4] += (double)(h[7] - h[6]); sum[5] += (double)(h[7] - h[8]);
+      if (FUSE1) mid += (double)(h[4] - h[3]);
+    }
+    if (FUSE1) {
+      double park = 0, fetch = 0;
+      for (int i = 0; i < nb; ++i) { const unsigned long long* h = host + (size_t)i * 10; park += (double)(h[9] - h[1]); fetch += (double)(h[0] - h[5]); }
+      fprintf(stderr, "TS (conv1_1 in the loader, strip %d: the second tile) second patch %.0f of the mainloop cycles; image patch parked %.0f of the load0 cycles; next fetch issued %.0f of the epilogue cycles\n",
+              strip, mid / nb, park / nb, fetch / nb);
     }
     fprintf(stderr, "TS launch %d <%d,%d,%d,%d> Cin %d Cout %d H %d up %d pool %d y32 %d blocks %d: setup %.0f load0 %.0f mainloop %.0f epilogue %.0f drain %.0f total %.0f\n",
             nlaunch, TH, BN, WM, WN, a.Cin, a.Cout, a.H, a.upsample, a.pool, a.y32 != nullptr, nb,
@@ -410,6 +600,10 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK(!a.usum || (a.y32 && a.umax && a.relu && a.W % 16 == 0));
   ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
+  if (a.img1) {                                           // conv1_1 inside the patch loader: the 512-pixel x 64-channel block only
+    ARG_CHECK(a.Cin == 64 && a.Cout == 64 && !a.upsample && a.w1frag && a.bias1);
+    return launch_conv_cfg<32, 64, 4, 1, true>(a, s);
+  }
   static const int force = tune_int("WCT_CONV_CFG", 0);   // tuning switch
   if (force == 1 && a.Cout % 128 == 0) return launch_conv_cfg<16, 128, 2, 2>(a, s);
   if (force == 2) return launch_conv_cfg<32, 64, 4, 1>(a, s);
