@@ -394,11 +394,28 @@ def main():
                 'traffic_unit': 'HBM bytes per launch; NOT measured in this run: the committed rocprofv3 PMC passes of this '
                                 'workload (%s)' % traffic_src if traffic else 'no committed PMC pass for this batch/size',
                 'algorithmic_bytes_per_launch': conv['bytes'] / max(1, conv['launches']),
-                'kernel': 'conv3x3_mfma_kernel (all launches of the class: the largest time class of the step; the tap launches -- 8 of 65 per step -- also take the transform\'s per-channel sums and maxima in their epilogue)',
+                'kernel': 'conv3x3_mfma_kernel, the generic instantiations <..., false> (all their launches: the largest time class of '
+                          'the step, 61 per frame set; the tap launches -- 8 of them -- also take the transform\'s per-channel sums and '
+                          'maxima in their epilogue).  Up to round 3 / profiles/r04_final the class had 65 launches: the four 64->64 '
+                          '@512^2 pooled conv1_2 launches of the content passes (0.25 of peak) now run as the instantiation '
+                          '<32,64,4,1,true> with conv1_1 inside the patch loader -- class conv12, next field -- and '
+                          'all_conv3x3_instantiations gives the figure over both for comparison with the earlier rounds',
                 'launches': conv['launches'], 'avg_launch_ms': conv['ms'] / max(1, conv['launches']),
                 'algorithmic_flops_per_frame': conv_flops_per_frame(S),
                 'algorithmic_gbytes_per_s': conv['bytes'] / (conv['ms'] * 1e-3) / 1e9 if conv['ms'] > 0 else 0.0,
             }
+            c12 = prof.get('conv12')
+            if c12 and c12['ms'] > 0:
+                a12 = c12['flops'] / (c12['ms'] * 1e-3) / 1e12
+                both = (conv['flops'] + c12['flops']) / ((conv['ms'] + c12['ms']) * 1e-3) / 1e12
+                line['roofline']['conv12'] = {
+                    'kernel': 'conv3x3_mfma_kernel<32,64,4,1,true>: conv1_1 (3->64, split-fp16 MFMA) computed into the halo patch, '
+                              'conv1_2 (64->64), 2x2 max-pool -- one launch instead of conv_first_kernel + conv3x3; algorithmic FLOPs of '
+                              'the two layers (the halo recomputation of conv1_1 is not counted)',
+                    'achieved': a12, 'frac': a12 / MFMA_F16_DENSE_PEAK_TFLOPS, 'launches': c12['launches'],
+                    'avg_launch_ms': c12['ms'] / max(1, c12['launches'])}
+                line['roofline']['all_conv3x3_instantiations'] = {
+                    'achieved': both, 'frac': both / MFMA_F16_DENSE_PEAK_TFLOPS, 'launches': conv['launches'] + c12['launches']}
             step_ms = 1e3 * dt / args.steps
             jac = prof['jacobi']
             jflops = sum(v['sweeps'] * jacobi_flops_per_sweep(c) for c, v in eig.items())

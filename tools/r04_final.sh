@@ -15,7 +15,7 @@ bash tools/gpu_pmc_lds.sh $TAG 2>&1 | tail -8
 import json,sys
 l=json.loads(sys.stdin.read().strip().splitlines()[-1])
 b=l['breakdown_ms_per_step']
-print('batch %3d: %7.1f frames/s  %6.2f ms/step | conv3x3 %5.2f conv_first %4.2f conv_last %4.2f cov %4.2f jacobi %5.2f apply %4.2f' % (l['config']['global_batch'], l['value'], l['ms_per_step'], b['conv3x3'], b['conv_first'], b['conv_last'], b['wct_cov'], b['jacobi'], b['wct_apply']))"; done ) > gpurun_out/${TAG}_batch_sweep.txt 2>&1
+print('batch %3d: %7.1f frames/s  %6.2f ms/step | conv3x3 %5.2f conv12 %4.2f conv_first %4.2f conv_last %4.2f cov %4.2f jacobi %5.2f apply %4.2f' % (l['config']['global_batch'], l['value'], l['ms_per_step'], b['conv3x3'], b.get('conv12', 0), b['conv_first'], b['conv_last'], b['wct_cov'], b['jacobi'], b['wct_apply']))"; done ) > gpurun_out/${TAG}_batch_sweep.txt 2>&1
 cat gpurun_out/${TAG}_batch_sweep.txt
 python tools/bench_configs.py 10 > gpurun_out/${TAG}_configs_latency.txt 2>&1; cat gpurun_out/${TAG}_configs_latency.txt
 WCT_BENCH_BACKEND=gloo WCT_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --batch 16 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_dryrun_2ranks_1gpu_gloo.json 2>/dev/null; cut -c1-200 gpurun_out/${TAG}_dryrun_2ranks_1gpu_gloo.json

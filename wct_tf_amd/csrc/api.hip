@@ -558,7 +558,7 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
       a.B = B; a.H = h; a.W = w; a.Cin = 64; a.Cout = 64; a.upsample = 0; a.relu = 1; a.pool = fuse;
       a.img1 = img; a.w1frag = c->first_w; a.bias1 = c->first_b; a.clamp01 = clamp01;
       const double px = (double)B * h * w, out_px = fuse ? (double)B * ((h + 1) / 2) * ((w + 1) / 2) : px;
-      ProfScope ps(c, 0, 2.0 * px * (27 * 64 + 9 * 64 * 64), px * 12 + out_px * 64 * 2 + 9.0 * 64 * 64 * 2);
+      ProfScope ps(c, 8, 2.0 * px * (27 * 64 + 9 * 64 * 64), px * 12 + out_px * 64 * 2 + 9.0 * 64 * 64 * 2);
       TRY(launch_conv3x3(a, c->stream));
     } else
     TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1, fuse, us, us ? umax[tap] : nullptr));

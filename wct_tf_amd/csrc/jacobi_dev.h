@@ -28,7 +28,6 @@ struct JacobiState {
   int seg_stop;          // number of launch segments whose rotations belong to this matrix (INT_MAX while it is still rotating)
   int pad2;              // 1: a diagonal within half a decade of the 1e-5 cut-off at the last residual measurement (first-order completion only)
 };
-constexpr int JACOBI_RESID_CHUNKS = 16;
 constexpr float JACOBI_SIG_FLOOR = 1e-4f;
 
 __device__ __forceinline__ int rr_idx(int pos, int step, int n) {

@@ -1217,58 +1217,22 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
 // mixed_w: weight of the kept-x-dropped couplings in the STRICT measure.  The second-order completion covers the block of
 // kept eigenvalues only, so when the stop threshold is raised for it (4e-2 instead of 1.5e-2) the couplings across the
 // cut-off keep their old bound: their squared measure is weighted by (4 / 1.5)^2.
-__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, JacobiState* st, float* partial, int C, float mixed_w = 1.f) {
-  __shared__ float red[4][4];
-  __shared__ float dg[1024];                           // |a_ii| of the whole matrix (C <= 1024)
-  __shared__ float idg[1024];                          // 1 / |a_ii| (0 for a zero diagonal: such pairs take the `mixed` form)
-  const int m = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
-  float* out = partial + ((size_t)m * JACOBI_RESID_CHUNKS + ch) * 4;
-  if (st[m].done) { if (tid == 0) { out[0] = 0.f; out[1] = 1.f; out[2] = 0.f; out[3] = 1.f; } return; }
-  const float* Am = A + (size_t)m * C * C;
-  const float floor_m = st[m].floor;
-  const int rows = (C + JACOBI_RESID_CHUNKS - 1) / JACOBI_RESID_CHUNKS;
-  const int p0 = ch * rows, p1 = min(C, p0 + rows);
-  int near = 0;
-  for (int i = tid; i < C; i += 256) {
-    const float d = fabsf(Am[(size_t)i * C + i]);
-    dg[i] = d;
-    idg[i] = d > 0.f ? 1.f / d : 0.f;
-    near |= (d > 3.3e-6f) & (d < 3e-5f);
-  }
-  // an eigenvalue within half a decade of the cut-off: its kept / dropped side can still change, and a pair of the kept
-  // block may really be a pair across the cut-off -- such a matrix keeps the old bound on ALL its couplings
-  const int near_any = __syncthreads_or(near);
-  const float kk_w = near_any ? mixed_w : 1.f;
-  // remembered for jacobi_finalize_kernel: such a matrix has only the first-order completion to pay for a late
-  // acceptance; every chunk computes the same flag from the same diagonal, chunk 0 records it
-  if (ch == 0 && tid == 0) st[m].pad2 = near_any ? 1 : 0;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int q = tid; q < C; q += 256) {                 // at most four columns per thread; rows stream coalesced
-    const float dq = dg[q], iq = idg[q];
-    const bool kq = dq > 1e-5f, sq = dq > floor_m;
-    if (q >= p0 && q < p1) { v[1] += kq ? 1.f : 0.f; v[3] += sq ? 1.f : 0.f; }
-#pragma unroll 4
-    for (int p = p0; p < p1; ++p) {
-      const float e = Am[(size_t)p * C + q];
-      const float dp = dg[p], ip = idg[p];             // LDS broadcast
-      const bool kp = dp > 1e-5f, sp = dp > floor_m;
-      const bool bigp = dp >= dq;
-      const float small = bigp ? dq : dp, ibig = bigp ? ip : iq;
-      const float e2 = p == q ? 0.f : 0.5f * e * e;
-      const float cos2 = e2 * ip * iq;
-      const float mixed = e2 * ibig * (ibig + (small < 1e-5f ? 0.01f * 1e5f : 0.f));
-      v[0] += (kp & kq) ? kk_w * cos2 : ((kp | kq) ? mixed_w * mixed : 0.f);
-      v[2] += (sp & sq) ? cos2 : ((sp | sq) ? mixed : 0.f);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
-    if ((tid & 63) == 0) red[j][tid >> 6] = v[j];
-  }
-  __syncthreads();
-  if (tid < 4) out[tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
-}
+// Round 4: the measurement walks 64 x 64 TILES of the upper triangle (the matrix is symmetric: an off-diagonal tile counts for
+// its mirror image as well, half the bytes and half the arithmetic of the row-chunk walk it replaces; the two diagonal segments
+// of a tile are 128 gathered values instead of the whole diagonal per block).  partial[m][tile][0..5] = strict kept-x-kept sum,
+// strict kept-x-dropped sum (weighted in jacobi_check_kernel: the `near` flag needs the whole diagonal), kept diagonals, lenient
+// sum, significant diagonals, near flag; jacobi_check_kernel (one wave per matrix) sums them over the tiles with a fixed lane ->
+// tile map and a fixed tree.  (Letting the block that finishes a matrix last evaluate the test -- a counter and a device-scope
+// fence per block -- saves the second launch and cost 2.5 ms per 32-pair step: the fence writes the XCD's L2 back, and the
+// tiles the update has just written are still dirty in it.)
+constexpr int JACOBI_RESID_T = 64;
+constexpr int JACOBI_RESID_MAXTILES = 136;             // C <= 1024: 16 x 17 / 2
+constexpr int JACOBI_RESID_STRIDE = 8;                 // floats per (matrix, tile)
+struct JacobiCheckArgs {
+  int mid;                   // 1: the test in the middle of a sweep (jacobi_check_mid)
+  float tol_max, tol_fn;
+  int buf, segs, lenient_from;
+};
 
 // done: 0 = still rotating, 1 = converged, 2 = failed (a non-finite element reached a pair problem).
 // Converged = the sweep saw no rotated pair above tol_max (the classical test: the matrix was already diagonal to
@@ -1277,48 +1241,126 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, Jacob
 // lenient_from: from this many completed sweeps on, a matrix whose SIGNIFICANT pairs were all below tol_max in the sweep
 // is done as well (what jacobi_finalize_kernel accepts when the budget runs out): the noise-level pairs of a
 // rank-deficient matrix never settle, and without this such a matrix always burns the whole sweep budget.
-__global__ void jacobi_check_kernel(JacobiState* st, const float* partial, int nmat, float tol_max, float tol_fn, int buf, int segs = 0,
-                                    int lenient_from = 1 << 30) {
-  const int m = threadIdx.x;
-  if (m >= nmat || st[m].done) return;
-  st[m].sweeps += 1;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < JACOBI_RESID_CHUNKS; ++c)
-    for (int j = 0; j < 4; ++j) v[j] += partial[((size_t)m * JACOBI_RESID_CHUNKS + c) * 4 + j];
+__device__ __forceinline__ void jacobi_check_end(JacobiState& s, const float (&v)[4], const JacobiCheckArgs& a) {
+  s.sweeps += 1;
   const float r2 = v[0] / fmaxf(v[1], 1.f);
-  st[m].r2 = r2;
-  st[m].r2l = v[2] / fmaxf(v[3], 1.f);
-  const unsigned bits = st[m].offmax;                   // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
-  if (bits >= 0x7f800000u || !(r2 < 3.0e38f)) st[m].done = 2;
-  else if (__uint_as_float(bits) < tol_max || (tol_fn > 0.f && r2 < tol_fn * tol_fn)) st[m].done = 1;
-  else if (st[m].sweeps >= lenient_from && __uint_as_float(st[m].offsig) < tol_max) st[m].done = 1;
-  if (st[m].done) { st[m].pad = buf; st[m].seg_stop = segs; }
-  st[m].last_sig = st[m].offsig;
-  st[m].floor = fmaxf(st[m].floor, JACOBI_SIG_FLOOR * __uint_as_float(st[m].dmax));
-  st[m].offmax = 0u;
-  st[m].offsig = 0u;
-  st[m].dmax = 0u;
+  s.r2 = r2;
+  s.r2l = v[2] / fmaxf(v[3], 1.f);
+  const unsigned bits = s.offmax;                       // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
+  if (bits >= 0x7f800000u || !(r2 < 3.0e38f)) s.done = 2;
+  else if (__uint_as_float(bits) < a.tol_max || (a.tol_fn > 0.f && r2 < a.tol_fn * a.tol_fn)) s.done = 1;
+  else if (s.sweeps >= a.lenient_from && __uint_as_float(s.offsig) < a.tol_max) s.done = 1;
+  if (s.done) { s.pad = a.buf; s.seg_stop = a.segs; }
+  s.last_sig = s.offsig;
+  s.floor = fmaxf(s.floor, JACOBI_SIG_FLOOR * __uint_as_float(s.dmax));
+  s.offmax = 0u;
+  s.offsig = 0u;
+  s.dmax = 0u;
 }
-
 // The same residual test in the MIDDLE of a sweep (tol_fn callers only): near the end the residual halves every third
 // of a sweep (tools/jacobi_block_order_proto.py), so a matrix that a full sweep would take 10x below the stop threshold
 // is usually below it half a sweep earlier; its remaining launches of the sweep turn into no-ops.  Touches nothing but
 // `done`, r2 / r2l and the sweep count (the half sweep counts as one).
-__global__ void jacobi_check_mid_kernel(JacobiState* st, const float* partial, int nmat, float tol_fn, int buf, int segs = 0) {
-  const int m = threadIdx.x;
-  if (m >= nmat || st[m].done) return;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < JACOBI_RESID_CHUNKS; ++c)
-    for (int j = 0; j < 4; ++j) v[j] += partial[((size_t)m * JACOBI_RESID_CHUNKS + c) * 4 + j];
+__device__ __forceinline__ void jacobi_check_mid(JacobiState& s, const float (&v)[4], const JacobiCheckArgs& a) {
   const float r2 = v[0] / fmaxf(v[1], 1.f);
-  if (st[m].offmax < 0x7f800000u && r2 < tol_fn * tol_fn) {       // finite so far and converged
-    st[m].r2 = r2;
-    st[m].r2l = v[2] / fmaxf(v[3], 1.f);
-    st[m].last_sig = st[m].offsig;
-    st[m].sweeps += 1;
-    st[m].done = 1;
-    st[m].pad = buf;
-    st[m].seg_stop = segs;
+  if (s.offmax < 0x7f800000u && r2 < a.tol_fn * a.tol_fn) {       // finite so far and converged
+    s.r2 = r2;
+    s.r2l = v[2] / fmaxf(v[3], 1.f);
+    s.last_sig = s.offsig;
+    s.sweeps += 1;
+    s.done = 1;
+    s.pad = a.buf;
+    s.seg_stop = a.segs;
+  }
+}
+
+// grid (tiles of the upper triangle, matrices)
+__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const JacobiState* st, float* partial, int C) {
+  constexpr int T = JACOBI_RESID_T;
+  __shared__ float dr[T], dc[T], ir[T], ic[T];
+  __shared__ float red[5][4];
+  const int m = blockIdx.y, tid = threadIdx.x;
+  if (st[m].done) return;                                // (jacobi_check_kernel skips the matrix as well)
+  const int ntr = (C + T - 1) / T;
+  int ti = 0, t = blockIdx.x;
+  while (t >= ntr - ti) { t -= ntr - ti; ++ti; }
+  const int tj = ti + t;
+  const bool diag = ti == tj;
+  const float* Am = A + (size_t)m * C * C;
+  const float floor_m = st[m].floor;
+  if (tid < 2 * T) {
+    const int i = (tid < T ? ti * T + tid : tj * T + tid - T);
+    const float d = i < C ? fabsf(Am[(size_t)i * C + i]) : 0.f;
+    (tid < T ? dr : dc)[tid & (T - 1)] = d;
+    (tid < T ? ir : ic)[tid & (T - 1)] = d > 0.f ? 1.f / d : 0.f;
+  }
+  __syncthreads();
+  // v: kept x kept, kept x dropped, kept diagonals, lenient, significant diagonals; near flag beside them
+  float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  int near = 0;
+  if (diag && tid < T && ti * T + tid < C) {
+    const float d = dr[tid];
+    v[2] = d > 1e-5f ? 1.f : 0.f;
+    v[4] = d > floor_m ? 1.f : 0.f;
+    // an eigenvalue within half a decade of the cut-off: its kept / dropped side can still change, and a pair of the kept
+    // block may really be a pair across the cut-off -- such a matrix keeps the old bound on ALL its couplings
+    near = (d > 3.3e-6f) & (d < 3e-5f);
+  }
+  // an ordered pair (p, q) weighs 1/2: an off-diagonal tile stands for its mirror image too
+  const float w = diag ? 0.5f : 1.f;
+  const int c4 = (tid & 15) * 4, gq = tj * T + c4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = (tid >> 4) + 16 * k, gp = ti * T + r;
+    if (gp < C && gq < C) {                              // (C is a multiple of 32: a group of four columns is inside or outside)
+      const f32x4 e4 = *reinterpret_cast<const f32x4*>(Am + (size_t)gp * C + gq);
+      const float dp = dr[r], ip = ir[r];
+      const bool kp = dp > 1e-5f, sp = dp > floor_m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dq = dc[c4 + j], iq = ic[c4 + j];
+        const bool kq = dq > 1e-5f, sq = dq > floor_m;
+        const bool bigp = dp >= dq;
+        const float small = bigp ? dq : dp, ibig = bigp ? ip : iq;
+        const float e2 = (diag && r == c4 + j) ? 0.f : w * e4[j] * e4[j];
+        const float cos2 = e2 * ip * iq;
+        const float mixed = e2 * ibig * (ibig + (small < 1e-5f ? 0.01f * 1e5f : 0.f));
+        v[0] += (kp & kq) ? cos2 : 0.f;
+        v[1] += (kp ^ kq) ? mixed : 0.f;
+        v[3] += (sp & sq) ? cos2 : ((sp | sq) ? mixed : 0.f);
+      }
+    }
+  }
+  const int near_any = __syncthreads_or(near);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
+    if ((tid & 63) == 0) red[j][tid >> 6] = v[j];
+  }
+  __syncthreads();
+  float* out = partial + ((size_t)m * JACOBI_RESID_MAXTILES + blockIdx.x) * JACOBI_RESID_STRIDE;
+  if (tid < 5) out[tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+  if (tid == 5) out[5] = near_any ? 1.f : 0.f;
+}
+
+// grid (matrices), one wave: the measurement's sums over the tiles, then the test (ck.mid: the one in the middle of a sweep)
+__global__ __launch_bounds__(64) void jacobi_check_kernel(JacobiState* st, const float* partial, int ntile, float mixed_w, JacobiCheckArgs ck) {
+  const int m = blockIdx.x, tid = threadIdx.x;
+  if (st[m].done) return;
+  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* pm = partial + (size_t)m * JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE;
+  for (int tt = tid; tt < ntile; tt += 64)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) a[j] += pm[tt * JACOBI_RESID_STRIDE + j];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+    for (int o = 32; o > 0; o >>= 1) a[j] += __shfl_xor(a[j], o, 64);
+  if (tid == 0) {
+    const bool near_m = a[5] > 0.f;
+    // remembered for jacobi_finalize_kernel: such a matrix has only the first-order completion to pay for a late acceptance
+    st[m].pad2 = near_m ? 1 : 0;
+    const float vv[4] = {(near_m ? mixed_w : 1.f) * a[0] + mixed_w * a[1], a[2], a[3], a[4]};
+    if (ck.mid) jacobi_check_mid(st[m], vv, ck); else jacobi_check_end(st[m], vv, ck);
   }
 }
 
@@ -1373,7 +1415,7 @@ size_t jacobi_workspace_bytes(int C, int nmat) {
   // widths) and the same again as fp16 hi/lo fragments, two generations of rotated pair problems (2 x C x M2 <= 128 C), the second matrix buffer (C^2); then state
   // words and residual partials
   return (size_t)nmat * ((size_t)9 * C * C + (size_t)128 * C) * sizeof(float) + 1024 +
-         (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_CHUNKS * 4 * sizeof(float));
+         (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE * sizeof(float));
 }
 
 // One group = a set of matrices on its own stream (the two halves of a batch run as two groups so
@@ -1566,6 +1608,14 @@ static void jacobi_enqueue_segment(JacobiGroup* grp, int ngrp, int C, int step_b
       jacobi_fused_launch<M2>(grp[g], C, step_begin, step < step_end, step, step > step_begin, step - 1, step == step_begin);
 }
 
+// residual measurement of the group's matrices (in P[cur]), then the test `ck`
+static void jacobi_measure(JacobiGroup& G, int C, const JacobiCheckArgs& ck) {
+  const int ntr = (C + JACOBI_RESID_T - 1) / JACOBI_RESID_T;
+  const int ntile = ntr * (ntr + 1) / 2;
+  hipLaunchKernelGGL(jacobi_resid_kernel, dim3(ntile, G.nmat), dim3(256), 0, G.stream, G.P[G.cur], G.st, G.resid, C);
+  hipLaunchKernelGGL(jacobi_check_kernel, dim3(G.nmat), dim3(64), 0, G.stream, G.st, G.resid, ntile, G.tol_fn > 2e-2f ? 7.1f : 1.f, ck);
+}
+
 template <int M2>
 static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
   constexpr int B = M2 / 2;
@@ -1611,16 +1661,14 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     if (mid) {
       for (int g = 0; g < ngrp; ++g)
         if (grp[g].tol_fn > 0.f) {
-          hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
-          hipLaunchKernelGGL(jacobi_check_mid_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, grp[g].tol_fn, grp[g].cur, grp[g].segs);
+          jacobi_measure(grp[g], C, JacobiCheckArgs{1, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, 1 << 30});
         }
       if ((rc = jacobi_segment_begin(grp, ngrp))) return rc;
       jacobi_enqueue_segment<M2>(grp, ngrp, C, half, nblk - 1, half, nblk);
       if ((rc = jacobi_segment_end<M2>(grp, ngrp, C, half, nblk - 1))) return rc;
     }
     for (int g = 0; g < ngrp; ++g) {
-      hipLaunchKernelGGL(jacobi_resid_kernel, dim3(JACOBI_RESID_CHUNKS, grp[g].nmat), dim3(256), 0, grp[g].stream, grp[g].P[grp[g].cur], grp[g].st, grp[g].resid, C, grp[g].tol_fn > 2e-2f ? 7.1f : 1.f);
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(64), 0, grp[g].stream, grp[g].st, grp[g].resid, grp[g].nmat, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, max_sweeps - 3);
+      jacobi_measure(grp[g], C, JacobiCheckArgs{0, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, max_sweeps - 3});
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
       for (int g = 0; g < ngrp; ++g) {
