@@ -81,6 +81,27 @@ __device__ __forceinline__ bool jacobi_rotation_cs(float app, float aqq, float a
   s = rot ? r * t : 0.f;
   return rot;
 }
+// the same with tan(theta) beside (c, s), for the scaled rotations of the register-resident pair problems (r4::strip_sets):
+// t is what the chain of a rotation set waits for (it is published as soon as it exists), (c, s) only feed the pivot lane's
+// own closed-form diagonals of the next set
+__device__ __forceinline__ bool jacobi_rotation_cst(float app, float aqq, float apq, float& c, float& s, float& tt) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
+  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
+  const float tau = 0.5f * (aqq - app);
+  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
+  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
+  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
+  tt = rot ? t : 0.f;
+  const float n2 = 1.f + t * t;
+  float r = __builtin_amdgcn_rsqf(n2);
+  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
+  c = rot ? r : 1.f;
+  s = rot ? r * t : 0.f;
+  return rot;
+}
 __device__ __forceinline__ void jacobi_rotation_stats(float app, float aqq, float apq, float floor_m, bool rot, float& off, float& sig) {
   const float den2 = fabsf(app * aqq);
   const float aapq = fabsf(apq);
@@ -395,14 +416,23 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
   // log entry of this lane's pair for the set in progress (pivot lanes; the others store into the dummy slot)
   unsigned char* logw = piv ? reinterpret_cast<unsigned char*>(simg) + k * 16 : xb + SX_DUMMY;
   const int log_step = piv ? 32 * 16 : 0;
-  float ppk = 0.f, qqk = 0.f, pqk = 0.f;                               // pair k's pivot block (pivot lanes)
+  // SCALED rotations (fast Givens): a rotation [x'; y'] = c [1 -t; t 1] [x; y] is applied as x <- x - a y, y <- y + b x -- one
+  // fma per output instead of a multiply and an fma -- and its factor c stays pending in a scale rho per INDEX: the stored
+  // value of S[i][j] is S[i][j] / (rho_i rho_j), that of Q[r][j] is Q[r][j] / rho_j, and a pair (p, q) publishes
+  // (a, b) = (t rho_q / rho_p, t rho_p / rho_q).  Only the pivot lanes know rho (of p_k, and of the q that is with them: it
+  // travels with q); they work on TRUE values -- closed-form diagonals, pivot element = rho_p rho_q x stored.  32 cosines
+  // >= 2^-1/2 each keep rho within [1.5e-5, 1]; strip_wave multiplies the scales back in when it scatters the cells.
+  float ppk = 0.f, qqk = 0.f, pqk = 0.f;                               // pair k's pivot block (pivot lanes), true values
+  float cpk = 1.f, spk = 0.f;                                          // the pair's rotation of the set in progress (pivot lanes)
+  float rp = 1.f, rq = 1.f;                                            // rho of p_k / of the q currently paired with it
   if (PWAVE) {
     __builtin_amdgcn_s_setprio(2);                                     // the chain of a set runs through this wave
     ppk = simg[k * 64 + k]; qqk = simg[(32 + k) * 64 + 32 + k]; pqk = simg[k * 64 + 32 + k];   // set 0 pairs k with 32 + k
-    float c, s, off, sig;
-    jacobi_rotation(ppk, qqk, pqk, floor_m, c, s, off, sig);
+    float off, sig;
+    jacobi_rotation(ppk, qqk, pqk, floor_m, cpk, spk, off, sig);
     if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
-    f32x2 r; r[0] = c; r[1] = s;
+    const float t0 = spk * __builtin_amdgcn_rcpf(cpk);                 // (no rotation: s = 0)
+    f32x2 r; r[0] = t0; r[1] = t0;
     *reinterpret_cast<f32x2*>(xb + a_csw) = r;
   }
   __syncthreads();                                                     // (the S image is free from here on)
@@ -462,37 +492,46 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
     f32x2 rl[W];
     static_for<W>([&](auto J) { constexpr int j = decltype(J)::value; rl[j] = *reinterpret_cast<const f32x2*>(xb + CUR * 256 + a_l[j]); });
     if (IN) take_rim(SC);
-    const float ck = rk[0], sk = rk[1];
+    const float ak = rk[0], bk = rk[1];
     float nqq[W], nqp[W];
     static_for<W>([&](auto J) {
       constexpr int j = decltype(J)::value, P = (j + S) % W;
-      const float c = rl[j][0], s = rl[j][1];
-      // columns (pair l) on the {S, Q} pairs as packed arithmetic, then rows (pair k) on the S halves
-      const f32x2 yp = c * R.Xpp[j] - s * R.Xpq[P], yq = s * R.Xpp[j] + c * R.Xpq[P];
-      const f32x2 yqp = c * R.Xqp[j] - s * R.Xqq[P], yqq = s * R.Xqp[j] + c * R.Xqq[P];
+      const float al = rl[j][0], bl = rl[j][1];
+      // columns (pair l) on the {S, Q} pairs as packed arithmetic, then rows (pair k) on the S halves: four packed and four
+      // scalar fma per cell
+      const f32x2 yp = R.Xpp[j] - al * R.Xpq[P], yq = R.Xpq[P] + bl * R.Xpp[j];
+      const f32x2 yqp = R.Xqp[j] - al * R.Xqq[P], yqq = R.Xqq[P] + bl * R.Xqp[j];
       f32x2 npp = yp, npq = yq;
-      npp[0] = ck * yp[0] - sk * yqp[0];  npq[0] = ck * yq[0] - sk * yqq[0];
-      nqp[j] = sk * yp[0] + ck * yqp[0];  nqq[j] = sk * yq[0] + ck * yqq[0];
+      npp[0] = yp[0] - ak * yqp[0];  npq[0] = yq[0] - ak * yqq[0];
+      nqp[j] = yqp[0] + bk * yp[0];  nqq[j] = yqq[0] + bk * yq[0];
       R.Xpp[j] = npp;  R.Xpq[P] = npq;
       R.Xqp[j][1] = yqp[1];  R.Xqq[P][1] = yqq[1];
     });
     constexpr int P0 = S % W;                                          // physical pair of column 0
     if (PWAVE) {
-      // pair k after this set (closed form from registers); partner diagonal of the next set = the q diagonal pair k + 1
-      // has just produced (lane k + 1 of this half-wave); next pivot element = this lane's freshly rotated cell (k, 0)
+      // pair k after this set (closed form from registers, true values); partner diagonal of the next set = the q diagonal pair
+      // k + 1 has just produced (lane k + 1 of this half-wave), and with it comes that q's scale; next pivot element = this
+      // lane's freshly rotated cell (k, 0), scaled back
+      const float ck = cpk, sk = spk;
       const float c2 = ck * ck, s2 = sk * sk, cs2 = 2.f * ck * sk;
       const float ppn = c2 * ppk - cs2 * pqk + s2 * qqk;
       const float qqn = s2 * ppk + cs2 * pqk + c2 * qqk;
+      const float rqn = ck * rq;
       // (a DPP wave shift: lane i reads lane i + 1, the wrap-around lane 31 <- 0 patched with a v_readlane: no LDS round
       // trip on the chain)
-      const int qi = __builtin_bit_cast(int, qqn);
+      const int qi = __builtin_bit_cast(int, qqn), ri = __builtin_bit_cast(int, rqn);
       const int shl = __builtin_amdgcn_update_dpp(qi, qi, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-      const int first = __builtin_amdgcn_readlane(qi, 0);
+      const int shr = __builtin_amdgcn_update_dpp(ri, ri, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+      const int first = __builtin_amdgcn_readlane(qi, 0), firstr = __builtin_amdgcn_readlane(ri, 0);
       const float nb = __builtin_bit_cast(float, k == 31 ? first : shl);
-      ppk = ppn; qqk = nb; pqk = R.Xpq[P0][0];
-      float c, s;
-      const bool rot = jacobi_rotation_cs(ppk, qqk, pqk, c, s);
-      f32x2 r; r[0] = c; r[1] = s;
+      rp = ck * rp;
+      rq = __builtin_bit_cast(float, k == 31 ? firstr : shr);
+      // (the ratios of the scales do not wait for the pivot element)
+      const float rqp = rq * __builtin_amdgcn_rcpf(rp), rpq = rp * __builtin_amdgcn_rcpf(rq), rpr = rp * rq;
+      ppk = ppn; qqk = nb; pqk = rpr * R.Xpq[P0][0];
+      float tt;
+      const bool rot = jacobi_rotation_cst(ppk, qqk, pqk, cpk, spk, tt);
+      f32x2 r; r[0] = tt * rqp; r[1] = tt * rpq;
       *reinterpret_cast<f32x2*>(xb + NX * 256 + a_csw) = r;
       *reinterpret_cast<f32x4*>(logw) = f32x4{ppk, qqk, pqk, rot ? 1.f : 0.f};
       logw += log_step;
@@ -529,6 +568,12 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
   body(std::integral_constant<int, 31 % LCM>{}, std::true_type{});     // set 31
   take_rim(std::integral_constant<int, 32 % LCM>{});                   // the arrangement of "set 32" = that of set 0
   if (PWAVE) __builtin_amdgcn_s_setprio(0);
+  // the scales of the 64 indices for strip_wave's scatter (the (a, b) slots of the buffer nobody reads any more: the last set
+  // read the other one, and a barrier lies between)
+  if (piv) {
+    *reinterpret_cast<float*>(xb + SX_CS + k * 4) = rp;
+    *reinterpret_cast<float*>(xb + SX_CS + (32 + k) * 4) = rq;
+  }
   // the statistics of the 32 x 32 logged rotations (the last set's are those of a rotation that is never applied: the
   // state of the pivots after the step), four per lane
 #pragma unroll
@@ -561,13 +606,17 @@ __device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned ch
   strip_sets<LAY, W, PWAVE>(R, xb, simg, t, floor_m, my_off, my_sig);
   __syncthreads();                                  // every lane has taken its last rim: the exchange area becomes the Q image
   constexpr int LCM = (W % 2) ? 2 * W : W, SF = 32 % LCM;
+  // the pending scales of the scaled rotations: S[i][j] = rho_i rho_j x stored, Q[r][j] = rho_j x stored (behind the Q image)
+  const float* rho = reinterpret_cast<const float*>(xb + Xchg<LAY>::CS);
+  const float rkp = rho[k], rkq = rho[B + k];
   static_for<W>([&](auto J) {
     constexpr int j = decltype(J)::value, P = (j + SF) % W;
     const int l = la[j];
-    simg[k * M2 + l] = R.Xpp[j][0];        simg[k * M2 + B + l] = R.Xpq[P][0];
-    simg[(B + k) * M2 + l] = R.Xqp[j][0];  simg[(B + k) * M2 + B + l] = R.Xqq[P][0];
-    qimg[k * M2 + l] = R.Xpp[j][1];        qimg[k * M2 + B + l] = R.Xpq[P][1];
-    qimg[(B + k) * M2 + l] = R.Xqp[j][1];  qimg[(B + k) * M2 + B + l] = R.Xqq[P][1];
+    const float rlp = rho[l], rlq = rho[B + l];
+    simg[k * M2 + l] = (rkp * rlp) * R.Xpp[j][0];        simg[k * M2 + B + l] = (rkp * rlq) * R.Xpq[P][0];
+    simg[(B + k) * M2 + l] = (rkq * rlp) * R.Xqp[j][0];  simg[(B + k) * M2 + B + l] = (rkq * rlq) * R.Xqq[P][0];
+    qimg[k * M2 + l] = rlp * R.Xpp[j][1];        qimg[k * M2 + B + l] = rlq * R.Xpq[P][1];
+    qimg[(B + k) * M2 + l] = rlp * R.Xqp[j][1];  qimg[(B + k) * M2 + B + l] = rlq * R.Xqq[P][1];
   });
 }
 
