@@ -435,7 +435,8 @@ def main():
                          'pivot wave) + fp32-MFMA tile updates',
                 'note': 'batched two-sided block Jacobi on the %d-level covariances (C = 512, 512, 256, 128, 64; content and style); '
                         'look-ahead launches {pair problems of step s, tile update of step s-1}; from 256 channels on the 64 x 64 pair '
-                        'problems are resident in REGISTERS (256 threads, 1 x W strips of cells, rim exchange through LDS; round 4); V '
+                        'problems are resident in REGISTERS (256 threads, 1 x W strips of cells, rim exchange through LDS, scaled '
+                        'rotations: one fma per output; four blocks of a launch per CU; round 4); V '
                         'resident in registers per launch segment from 24 matrices per solve on; second-order completion of the '
                         'spectral functions; second-largest time class' % len(LEVELS)}
             line['breakdown_ms_per_step'] = {k: v['ms'] / args.steps for k, v in prof.items()}
