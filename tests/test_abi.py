@@ -158,3 +158,14 @@ def test_t7_reader_matches_reference_torchfile():
     with pytest.raises(ValueError):
         from wct_tf_amd.t7 import T7Reader
         T7Reader(memoryview(b'\x04\x00\x00\x00\x01\x00'), 8).read()      # truncated
+
+
+def test_profiling_class_list_matches_the_header():
+    """The Python mirror's class names (one per id) and the array length the C ABI declares (WCT_PROF_CLASSES) move together."""
+    import re
+    from wct_tf_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'wct_hip.h')).read()
+    n = int(re.search(r'#define\s+WCT_PROF_CLASSES\s+(\d+)', hdr).group(1))
+    assert n == len(_lib.PROF_CLASSES) == 9
+    assert _lib.PROF_CLASSES[0] == 'conv3x3' and _lib.PROF_CLASSES[8] == 'conv12'
+    assert len(set(_lib.PROF_CLASSES)) == n
