@@ -375,7 +375,7 @@ constexpr size_t lds_bytes(int has_d, int has_u, int first, int step_d) {
       if (!first && need < stage) need = stage;
     }
   }
-  const size_t u = 2 * M2 * (M2 + 1) * F;                                              // tile, one rotation matrix
+  const size_t u = (M2 * M2 + M2 * (M2 + 4)) * F;                                      // one rotation log (linear), T transposed
   if (has_u && need < u) need = u;
   return need;
 }
@@ -841,10 +841,10 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
 }
 
 // U part: one task of the tile update (see jacobi_fused_u) by 256 threads: a wave owns a 16-row strip of the 64 x 64 tile
-// (four 16 x 16 MFMA tiles); per output tile the operands, k-slots and MFMA order are those of the 1024-thread version.
+// (four 16 x 16 MFMA tiles).
 template <int M2>
 __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int task, float* jsm) {
-  constexpr int B = M2 / 2, PITCH = M2 + 1, NW = M2 / 16, FR = M2 * M2, NV = FR / 4 / NT;
+  constexpr int B = M2 / 2, NW = M2 / 16, FR = M2 * M2, NV = FR / 4 / NT;
   static_assert(NT / 64 == NW, "one 16-row strip per wave");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid >= NT) return;                         // launched beside 512-thread pair problems: waves 4..7 have no part (before any barrier)
@@ -870,38 +870,16 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
   int hi, hj, gi = 0, gj = 0;
   block_pair(h, p.step_u, nblk, hi, hj);
   if (!is_v) block_pair(g, p.step_u, nblk, gi, gj);
-  // LDS: the tile and ONE rotation matrix (33 KB: with the 39 KB of a pair problem four blocks of a {D, U} launch fit a
-  // CU); Q_g waits in registers and replaces Q_h in LDS when T replaces X
-  float* Xs = jsm;
-  float* Qs = Xs + M2 * PITCH;
-  f32x4 gv[NV];
-  {
-    const float* X = is_v ? p.V + m * cc : p.Pr + m * cc;
-    f32x4 xv[NV], hv[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * NT, e4 = f * 4, lr = e4 / M2, lc = e4 % M2;
-      const int gr = is_v ? g * M2 + lr : pair_index<B>(lr, gi, gj);
-      xv[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * C + pair_index<B>(lc, hi, hj));
-      hv[i] = gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!is_v) {                                  // (a V task takes Q_h as fp16 fragments straight from the log)
-        hv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + h) * FR + e4);
-        gv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + g) * FR + e4);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * NT, e4 = f * 4, lr = e4 / M2, lc = e4 % M2;
-      int qr, qc;
-      qfrag_rc<M2>(f, qr, qc);                      // the rotations arrive in fragment order
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        Xs[lr * PITCH + lc + j] = xv[i][j];
-        if (!is_v) Qs[(qr + j) * PITCH + qc] = hv[i][j];
-      }
-    }
-  }
-  __syncthreads();
+  // Operands by the shortest way (round 4): the MFMA k-slot of lane-quarter lq in step (gg, s) is k = 16 gg + 4 lq + s (any
+  // order of k serves, as long as both operands use it), so that a lane's four consecutive steps take four CONSECUTIVE k:
+  //   * X: the wave's own 16-row strip, four 16-byte loads per lane straight from the matrix -- no LDS;
+  //   * Q_g (second product, A operand): the rotation log is stored in exactly this unit order (qfrag_rc: unit f = rows
+  //     16 t + 4 (l >> 4) .. + 3 of column 16 mt + (l & 15)) -- the wave's quarter, four units per lane, straight from the log;
+  //   * Q_h (first product, B operand): every wave needs all of it: a LINEAR copy of the log in LDS, read back one unit at a time;
+  //   * T = X Q_h goes through LDS transposed (T^t[j][k], pitch 68: 16-byte writes from the accumulators, 16-byte reads).
+  // 40 LDS instructions per thread and task instead of 270, two barriers instead of three; 33.8 KB (four blocks of a {D, U}
+  // launch per CU).  A V task reads its strip from V directly and uses no LDS at all.
+  constexpr int P4 = M2 + 4;
   const int ti = wave, li = lane & 15, lq = lane >> 4;
   f32x4 acc[NW];
 #pragma unroll
@@ -909,11 +887,19 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
   if (is_v) {
     constexpr int NCH = M2 / 32;
     const half_t* q16 = p.Qr16 + ((size_t)m * npair + h) * (2 * FR);
+    float* Vm = p.V + m * cc;
+    const float* Vrow = Vm + (size_t)(g * M2 + 16 * ti + li) * C;
+    f32x4 vx[NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)               // qfrag16_k(c, lq, 4 hf .. 4 hf + 3): four consecutive columns of one block
+        vx[c][hf] = *reinterpret_cast<const f32x4*>(Vrow + pair_index<B>(qfrag16_k<M2>(c, lq, 4 * hf), hi, hj));
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       float x[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = Xs[(16 * ti + li) * PITCH + qfrag16_k<M2>(c, lq, j)];
+      for (int j = 0; j < 8; ++j) x[j] = vx[c][j >> 2][j & 3];
       half8 bh, bl;
       split_f16x8(x, bh, bl);
 #pragma unroll
@@ -925,40 +911,57 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
         acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[tj], 0, 0, 0);
       }
     }
-    float* Vm = p.V + m * cc;
 #pragma unroll
     for (int tj = 0; tj < NW; ++tj)
       *reinterpret_cast<f32x4*>(Vm + (size_t)(g * M2 + 16 * ti + li) * C + pair_index<B>(16 * tj + 4 * lq, hi, hj)) = acc[tj];
     return;
   }
-#pragma unroll 2
-  for (int kk = 0; kk < M2; kk += 4) {      // T = X Qh
-    const float a = Xs[(16 * ti + li) * PITCH + kk + lq];
+  float* Qh = jsm;                                  // [FR] the log of pair h, unit order
+  float* Tt = jsm + FR;                             // [M2][P4] T transposed
+  f32x4 xa[NW], ga[NW];
+  {
+    const float* Xrow = p.Pr + m * cc + (size_t)pair_index<B>(16 * ti + li, gi, gj) * C;
+    const float* Qg = p.Qr + ((size_t)m * npair + g) * FR;
+    const float* Qhg = p.Qr + ((size_t)m * npair + h) * FR;
+    f32x4 hv[NV];
 #pragma unroll
-    for (int tj = 0; tj < NW; ++tj)
-      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Qs[(kk + lq) * PITCH + 16 * tj + li], acc[tj], 0, 0, 0);
+    for (int gg = 0; gg < NW; ++gg) {
+      xa[gg] = *reinterpret_cast<const f32x4*>(Xrow + pair_index<B>(16 * gg + 4 * lq, hi, hj));
+      ga[gg] = *reinterpret_cast<const f32x4*>(Qg + (size_t)((ti * NW + gg) * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) hv[i] = *reinterpret_cast<const f32x4*>(Qhg + (size_t)(tid + i * NT) * 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(Qh + (tid + i * NT) * 4) = hv[i];
   }
   __syncthreads();
 #pragma unroll
-  for (int tj = 0; tj < NW; ++tj) {
+  for (int gg = 0; gg < NW; ++gg) {         // T = X Qh
+    f32x4 b4[NW];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Xs[(16 * ti + 4 * lq + r) * PITCH + 16 * tj + li] = acc[tj][r];
+    for (int tj = 0; tj < NW; ++tj) b4[tj] = *reinterpret_cast<const f32x4*>(Qh + ((tj * NW + gg) * 64 + lane) * 4);
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+      for (int tj = 0; tj < NW; ++tj)
+        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[gg][sx], b4[tj][sx], acc[tj], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tj = 0; tj < NW; ++tj) {         // the lane holds T[16 ti + 4 lq .. + 3][16 tj + li]
+    *reinterpret_cast<f32x4*>(Tt + (16 * tj + li) * P4 + 16 * ti + 4 * lq) = acc[tj];
     acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    int qr, qc;
-    qfrag_rc<M2>(tid + i * NT, qr, qc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Qs[(qr + j) * PITCH + qc] = gv[i][j];
-  }
   __syncthreads();
-#pragma unroll 2
-  for (int kk = 0; kk < M2; kk += 4) {      // Y = Qg^T T
-    const float a = Qs[(kk + lq) * PITCH + 16 * ti + li];
 #pragma unroll
-    for (int tj = 0; tj < NW; ++tj)
-      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Xs[(kk + lq) * PITCH + 16 * tj + li], acc[tj], 0, 0, 0);
+  for (int gg = 0; gg < NW; ++gg) {         // Y = Qg^T T
+    f32x4 b4[NW];
+#pragma unroll
+    for (int tj = 0; tj < NW; ++tj) b4[tj] = *reinterpret_cast<const f32x4*>(Tt + (16 * tj + li) * P4 + 16 * gg + 4 * lq);
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+      for (int tj = 0; tj < NW; ++tj)
+        acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[gg][sx], b4[tj][sx], acc[tj], 0, 0, 0);
   }
   float* Pw = p.Pw + m * cc;
 #pragma unroll
