@@ -364,15 +364,14 @@ constexpr int SX_LOG_B = 32 * 32 * 16;
 // bytes, guard words behind them.
 template <int M2, int LAY>
 constexpr size_t lds_bytes(int has_d, int has_u, int first, int step_d) {
-  constexpr size_t B = M2 / 2, F = sizeof(float);
+  constexpr size_t F = sizeof(float);
   size_t need = 0;
   if (has_d) {
     if (step_d < 0) need = 2 * M2 * (M2 + 1) * 2 * F + 4 * M2 * F;                     // intra sets: two {S, Q} images, D, O, dummy
     else {
       need = M2 * M2 * F + Xchg<LAY>::BYTES;                                           // S image, exchange area
       if (need < 2 * M2 * M2 * F) need = 2 * M2 * M2 * F;                              // S and Q images of the epilogue
-      const size_t stage = (M2 * (M2 + 1) + 2 * M2 * (B + 1)) * F;                     // look-ahead: X (then W), Q1, Q2
-      if (!first && need < stage) need = stage;
+      (void)first;                                                                     // (look-ahead: W sits in the exchange area)
     }
   }
   const size_t u = (M2 * M2 + M2 * (M2 + 4)) * F;                                      // one rotation log (linear), T transposed
@@ -671,74 +670,64 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       const int cc = (clo ? h1 : h2) * B + (clo ? c : c - B);
       sv[i] = (rlo == clo || same) ? src[rr * M2 + cc] : 0.f;
     }
-    float* Xs = jsm;                                // [M2][M2 + 1]  tile (g1, g2) of the state before U(step_u)
-    float* Q1s = Xs + M2 * (M2 + 1);                // [M2][B + 1]   columns h1 of Q_g1
-    float* Q2s = Q1s + M2 * (B + 1);                // [M2][B + 1]   columns h2 of Q_g2
-    float* Ws = Xs;                                 // [B][M2 + 1]   Q_g1[:, h1]^T X -- over X, once every wave is done with X
-    constexpr int NV = FR / 4 / NT;                 // float4 per thread of a 64 x 64 tile
-    f32x4 xv[NV], qv[NV];
-    float* Qdst[NV];
-    int xr[NV], xc[NV];
+    // W = Q_g1[:, h1]^T X (B x M2: 8 MFMA tiles over the waves, the jobs of a wave share their tile row), then crit = W
+    // Q_g2[:, h2] (B x B: one tile per wave 0..3).  Operands as in fused_u: k-slot 16 g + 4 lq + s, so the rotation matrices come
+    // straight from the logs in their unit order, X from the MIRROR tile (g2, g1) of the symmetric state (four consecutive k of
+    // one column = four consecutive floats of a row there), and only W passes through LDS (row-major, pitch 68, in the still
+    // idle exchange area): one barrier instead of three, no staging of X / Q1 / Q2.
+    constexpr int NJ = (B / 16) * NW / NWAVES, P4 = M2 + 4;
+    static_assert(NW % NJ == 0, "the jobs of a wave lie in one tile row of W");
+    float* Ws = jsm + FR;                           // [B][P4]
+    const int li = lane & 15, lq = lane >> 4;
+    const int trw = (wave * NJ) / NW;               // tile row of this wave's W jobs
+    const int trc = wave / (B / 16), tcc = wave % (B / 16);      // its crit tile (waves 0..3)
+    f32x4 a4[NW], xb4[NJ][NW], q2[NW];
     if (!same) {
       int b1i, b1j, b2i, b2j;
       block_pair(g1, p.step_u, nblk, b1i, b1j);
       block_pair(g2, p.step_u, nblk, b2i, b2j);
       const float* Pm = p.Pr + (size_t)m * C * C;
+      const float* Q1 = p.Qr + ((size_t)m * npair + g1) * FR;
+      const float* Q2 = p.Qr + ((size_t)m * npair + g2) * FR;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int idx = tid + i * NT, se = idx * 4;
-        xr[i] = se / M2; xc[i] = se % M2;
-        xv[i] = *reinterpret_cast<const f32x4*>(Pm + (size_t)pair_index<B>(xr[i], b1i, b1j) * C + pair_index<B>(xc[i], b2i, b2j));
-        // Q columns: M2 x B floats per side = FR / 8 float4 (the fragments of that half); first half of the indices
-        // fetches Q_g1, second half Q_g2
-        const bool one = idx < FR / 8;
-        const int t2 = one ? idx : idx - FR / 8;
-        const int f = (one ? h1 : h2) * (FR / 8) + t2;
-        int qr, qc;
-        qfrag_rc<M2>(f, qr, qc);
-        qc -= (one ? h1 : h2) * B;
-        qv[i] = *reinterpret_cast<const f32x4*>(p.Qr + ((size_t)m * npair + (one ? g1 : g2)) * FR + (size_t)f * 4);
-        Qdst[i] = (one ? Q1s : Q2s) + qr * (B + 1) + qc;
+      for (int gg = 0; gg < NW; ++gg) {
+        a4[gg] = *reinterpret_cast<const f32x4*>(Q1 + (size_t)(((2 * h1 + trw) * NW + gg) * 64 + lane) * 4);
+#pragma unroll
+        for (int jb = 0; jb < NJ; ++jb) {
+          const int tj = (wave * NJ + jb) % NW;
+          xb4[jb][gg] = *reinterpret_cast<const f32x4*>(Pm + (size_t)pair_index<B>(16 * tj + li, b2i, b2j) * C + pair_index<B>(16 * gg + 4 * lq, b1i, b1j));
+        }
+        q2[gg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wave < (B / 16) * (B / 16))
+          q2[gg] = *reinterpret_cast<const f32x4*>(Q2 + (size_t)(((2 * h2 + tcc) * NW + gg) * 64 + lane) * 4);
       }
     }
     if (p.st[m].done) return;                       // (block-uniform)
     floor_m = p.st[m].floor;
     JTS(1);
     f32x4 crit = {0.f, 0.f, 0.f, 0.f};
-    const int li = lane & 15, lq = lane >> 4;
     if (!same) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
+      for (int jb = 0; jb < NJ; ++jb) {
+        const int tj = (wave * NJ + jb) % NW;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { Xs[xr[i] * (M2 + 1) + xc[i] + j] = xv[i][j]; Qdst[i][j * (B + 1)] = qv[i][j]; }
+        for (int gg = 0; gg < NW; ++gg)
+#pragma unroll
+          for (int sx = 0; sx < 4; ++sx) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[gg][sx], xb4[jb][gg][sx], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ws[(16 * trw + 4 * lq + r) * P4 + 16 * tj + li] = acc[r];
+      }
       __syncthreads();
       JTS(2);
-      constexpr int NJ = (B / 16) * NW / NWAVES;                        // W = Q_g1[:, h1]^T X   (B x M2): 8 tiles over the waves
-      f32x4 wacc[NJ];
+      if (wave < (B / 16) * (B / 16)) {
 #pragma unroll
-      for (int jb = 0; jb < NJ; ++jb) {
-        const int job = wave * NJ + jb, tr = job / NW, tj = job % NW;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int kk = 0; kk < M2; kk += 4)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Q1s[(kk + lq) * (B + 1) + 16 * tr + li], Xs[(kk + lq) * (M2 + 1) + 16 * tj + li], acc, 0, 0, 0);
-        wacc[jb] = acc;
-      }
-      __syncthreads();                              // X has been read by every wave: W takes its place
+        for (int gg = 0; gg < NW; ++gg) {
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(Ws + (16 * trc + li) * P4 + 16 * gg + 4 * lq);
 #pragma unroll
-      for (int jb = 0; jb < NJ; ++jb) {
-        const int job = wave * NJ + jb, tr = job / NW, tj = job % NW;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Ws[(16 * tr + 4 * lq + r) * (M2 + 1) + 16 * tj + li] = wacc[jb][r];
+          for (int sx = 0; sx < 4; ++sx) crit = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[sx], q2[gg][sx], crit, 0, 0, 0);
+        }
       }
-      __syncthreads();
-      if (wave < (B / 16) * (B / 16)) {                                 // crit = W Q_g2[:, h2]   (B x B): one tile per wave
-        const int tr = wave / (B / 16), tc = wave % (B / 16);
-#pragma unroll 4
-        for (int kk = 0; kk < M2; kk += 4)
-          crit = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * tr + li) * (M2 + 1) + kk + lq], Q2s[(kk + lq) * (B + 1) + 16 * tc + li], crit, 0, 0, 0);
-      }
-      __syncthreads();                              // the staging area becomes the image
       JTS(3);
     }
 #pragma unroll
