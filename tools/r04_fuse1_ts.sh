@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round 4, GPU box: phase timing (-DCONV_TS library built beforehand as wct_tf_amd/libwct_ts.so) of the conv launches of one
-# 32-pair step, conv1_1 inside the loader on / off.
+# 32-pair step, conv1_1 inside the loader on / off.  Build it here first (hipcc cross-compiles; the .so travels with gpurun):
+#   cd wct_tf_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCONV_TS -c conv.hip -o /tmp/conv_ts.o &&
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o ../libwct_ts.so api.o /tmp/conv_ts.o wct.o coral.o train.o
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 cp wct_tf_amd/libwct_hip.so /tmp/lib_keep.so

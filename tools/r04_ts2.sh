@@ -1,5 +1,7 @@
 #!/bin/bash
-# phase timing of the pair-problem blocks with the -DJACOBI_TS library built beforehand (wct_tf_amd/libwct_jts.so)
+# phase timing of the pair-problem blocks with the -DJACOBI_TS library built beforehand (wct_tf_amd/libwct_jts.so):
+#   cd wct_tf_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DJACOBI_TS -c wct.hip -o /tmp/wct_ts.o &&
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o ../libwct_jts.so api.o conv.o /tmp/wct_ts.o coral.o train.o
 cd $GRAFT_REPO_ROOT
 cp wct_tf_amd/libwct_hip.so /tmp/libwct_hip.so.keep
 cp wct_tf_amd/libwct_jts.so wct_tf_amd/libwct_hip.so
