@@ -124,6 +124,9 @@ class Context(object):
         a = f32(mats)
         if a.ndim == 2:
             a = a[None]
+        # wct_eigh wants a matrix that is symmetric to the bit (include/wct_hip.h); (a + a^T) / 2 is, and leaves a symmetric
+        # input unchanged
+        a = np.ascontiguousarray(0.5 * (a + a.transpose(0, 2, 1)), np.float32)
         n, c, _ = a.shape
         evals = np.empty((n, c), np.float32)
         evecs = np.empty((n, c, c), np.float32)
