@@ -25,6 +25,7 @@ fp32-MFMA rate of its tile updates against the 157.3 TFLOP/s peak, and `hard_spe
 that leg.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -135,12 +136,29 @@ def cpu_baseline(size, weights, alpha):
     path = TorchPath(weights)
     c = synthetic_image(1000, size, size)
     s = synthetic_image(2000, size, size)
-    path.stylize(c, s, LEVELS, alpha, 'tf')
+    # where the reference tree is present (the build container; WCT_REFERENCE overrides the
+    # path) the transform timed is the reference's OWN wct_np, lifted out of its ops.py and executed -- wct_np(eps=0) +
+    # (1 - alpha) mc is the graph's wct_tf (tests/golden/wct_tf_reference.npz pins that) -- `kind: reference`; on a box
+    # without the tree (the GPU box) it is the restatement oracle.wct_tf -- `kind: port`.
+    transform, kind = None, 'port'
+    ref_ops = os.path.join(os.environ.get('WCT_REFERENCE', '/root/reference'), 'ops.py')
+    if os.path.exists(ref_ops):
+        try:
+            from oracle.make_golden import lift_function
+            ref_wct_np = lift_function(ref_ops, 'wct_np')
+
+            def transform(fc, fs, a):
+                mc = fc.reshape(-1, fc.shape[-1]).mean(0, dtype=np.float32)
+                return np.float32(ref_wct_np(fc[None], fs[None], a, 0.0) + np.float32(1 - a) * mc)
+            kind = 'reference'
+        except Exception:
+            transform, kind = None, 'port'
+    path.stylize(c, s, LEVELS, alpha, 'tf', transform=transform)
     times, t_transform = [], []
     for _ in range(5):
         timers = {}
         t0 = time.time()
-        path.stylize(c, s, LEVELS, alpha, 'tf', timers=timers)
+        path.stylize(c, s, LEVELS, alpha, 'tf', timers=timers, transform=transform)
         times.append(time.time() - t0)
         t_transform.append(timers['transform_s'])
     med = sorted(times)[len(times) // 2]
@@ -150,14 +168,15 @@ def cpu_baseline(size, weights, alpha):
         blas = max([p.get('num_threads', 0) for p in threadpool_info() if p.get('user_api') == 'blas'] or [0])
     except Exception:
         blas = 0
-    return {'value': 1.0 / med, 'unit': 'frames/s', 'cores': max(torch.get_num_threads(), blas), 'kind': 'port',
+    what = ("the reference's own wct_np(eps=0) + (1-alpha) mc lifted from its ops.py (= its wct_tf graph), LAPACK SVD" if kind == 'reference'
+            else "oracle.wct_tf, the RESTATEMENT of the reference's wct_tf/wct_np (no reference tree on this box), LAPACK SVD")
+    return {'value': 1.0 / med, 'unit': 'frames/s', 'cores': max(torch.get_num_threads(), blas), 'kind': kind,
             'host_cores': os.cpu_count(), 'torch_threads': torch.get_num_threads(), 'blas_threads': blas,
             # part (i), the reference's transform in NumPy (five whiten-colour transforms per frame, LAPACK
             # SVD), reported separately from part (ii), the torch-CPU stand-in for the CPU-TF conv stack
             'transform_s': med_t, 'conv_standin_s': med - med_t,
-            'sample': '1 warm-up + median of 5 frames %dx%d, 5-level, alpha %.1f: NumPy transform (oracle.wct_tf, the RESTATEMENT of the reference\'s '
-                      'wct_tf/wct_np, LAPACK SVD) + torch-CPU stand-in for the CPU-TF conv stack; %.2f s per frame '
-                      '(min %.2f, max %.2f)' % (size, size, alpha, med, min(times), max(times))}
+            'sample': '1 warm-up + median of 5 frames %dx%d, 5-level, alpha %.1f: NumPy transform (%s) + torch-CPU stand-in for the '
+                      'CPU-TF conv stack; %.2f s per frame (min %.2f, max %.2f)' % (size, size, alpha, what, med, min(times), max(times))}
 
 
 def real_image_leg(ctx, alpha, n=10):
@@ -273,7 +292,7 @@ def main():
     # WCT_BENCH_FORCE_OVERLAP=1: run the event protocol of the overlapped gather on a single rank too (tests)
     overlap = (world > 1 and backend == 'nccl') or bool(os.environ.get('WCT_BENCH_FORCE_OVERLAP'))
 
-    def measure(total_pairs, steps, warmup, prof_on):
+    def measure(total_pairs, steps, warmup, prof_on, gather_once=False):
         """`steps` timed steps of `total_pairs` pairs per step sharded over the ranks: (seconds [max over ranks], pairs
         of this rank, per-class profile or None, eigensolver statistics or None)"""
         lo, hi = shard_range(total_pairs, world, rank)                     # contiguous shard of the global batch
@@ -340,18 +359,41 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         ctx.prof_enable(False)
+        info = {'rank_ms_per_step': [1e3 * dt / max(1, steps)]}
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)                                      # every rank's own clock (min / max go into the line)
+            info['rank_ms_per_step'] = [1e3 * float(x.item()) / max(1, steps) for x in every]
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
             if rank == 0:
                 assert state['frames'] is not None and state['frames'].shape[0] == total_pairs
+        # checksum of the frames of the LAST step as rank 0 holds them (N > 1: the gathered tensor).  The inputs are a function
+        # of the global pair index alone and a frame does not depend on the batch it is computed in (tested bit for bit), so
+        # the digest of `total_pairs` pairs is the same for every N: a wrong shard offset or gather order changes it.
+        if rank == 0 and steps + warmup > 0:
+            last = state['frames'] if world > 1 else d_out[(state['k'] - 1) & 1]
+            info['frames_sha256'] = hashlib.sha256(last.cpu().numpy().tobytes()).hexdigest()
+            info['frames'] = int(last.shape[0])
+        if world > 1 and gather_once:
+            # the exchange step alone, once, NOT overlapped: a barrier, then the gather of the last step's frames, timed on
+            # the host around a device synchronisation (max over the ranks)
+            barrier()
+            k = (state['k'] - 1) & 1
+            t0 = time.perf_counter()
+            gather_frames(d_out[k] if backend == 'nccl' else d_out[k].cpu(), world, rank, n_items=total_pairs)
+            torch.cuda.synchronize()
+            tg = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            info['gather_ms_unoverlapped'] = 1e3 * float(tg.item())
+            info['gather_bytes_per_rank'] = int(d_out[k].numel())
         prof = ctx.prof_read() if prof_on else None
-        return dt, n_local, prof, ctx.eig_stats()
+        return dt, n_local, prof, ctx.eig_stats(), info
 
     strong = args.global_batch > 0
     total_pairs = args.global_batch if strong else args.batch * world
-    dt, n_local, prof, eig = measure(total_pairs, args.steps, args.warmup, not args.no_prof)
+    dt, n_local, prof, eig, info = measure(total_pairs, args.steps, args.warmup, not args.no_prof, gather_once=world > 1)
     # the same steps without the per-class events (they cost 1-2 %): reported beside the headline, never instead of it
     dt_np = None
     if not args.no_prof:
@@ -360,10 +402,29 @@ def main():
     strong_rec = None
     if world > 1 and not strong:
         g = 64
-        dts, _, _, _ = measure(g, args.steps, args.warmup, False)
+        dts, _, _, _, sinfo = measure(g, args.steps, args.warmup, False, gather_once=True)
         strong_rec = {'global_batch': g, 'pairs_per_gpu_per_step': g / world, 'value': g * args.steps / dts, 'unit': 'frames/s',
                       'ms_per_step': 1e3 * dts / args.steps, 'scaling': 'strong',
-                      'note': 'BASELINE configs[3]: 64 frames per step sharded over the GPUs, one RCCL gather per step'}
+                      'rank_ms_per_step_min_max': [min(sinfo['rank_ms_per_step']), max(sinfo['rank_ms_per_step'])],
+                      'gather_ms_unoverlapped': sinfo.get('gather_ms_unoverlapped'),
+                      'gather_bytes_per_rank': sinfo.get('gather_bytes_per_rank'),
+                      'frames_sha256': sinfo.get('frames_sha256'),
+                      'note': 'BASELINE configs[3]: 64 frames per step sharded over the GPUs, one RCCL gather per step (overlapped with '
+                              'the next step in the timed loop; gather_ms_unoverlapped = the same exchange once on its own); '
+                              'frames_sha256 = digest of the 64 gathered frames of the last step: the same for every N, and equal '
+                              'to configs3_projection.frames_sha256 of an N = 1 line'}
+    # N = 1: what configs[3] would take -- 64 pairs per step over 8 GPUs is 8 pairs per GPU: the batch-8 step of THIS GPU
+    # against its own time for all 64 pairs (two 32-pair calls); the gather is not in it
+    proj = None
+    if world == 1 and not strong and not args.shared_style and args.batch == 32:
+        dt8 = measure(8, args.steps, 2, False)[0]
+        dt64, _, _, _, i64 = measure(64, max(1, args.steps // 2), 1, False)
+        ms8, ms64 = 1e3 * dt8 / args.steps, 1e3 * dt64 / max(1, args.steps // 2)
+        proj = {'batch8_ms_per_step': ms8, 'batch8_frames_per_s': 8e3 / ms8, 'one_gpu_64_pairs_ms': ms64,
+                'projected_speedup_8_gpus': ms64 / ms8, 'target': 6.0, 'frames_sha256': i64.get('frames_sha256'),
+                'note': 'BASELINE configs[3] (64 frames over 8 GPUs = 8 pairs per GPU) projected from ONE GPU: time of 64 pairs here / '
+                        'time of an 8-pair step here, before the 6.3 MB-per-rank gather; frames_sha256 = digest of those 64 frames '
+                        '(what the `strong` record of an N > 1 line must reproduce)'}
 
     if rank == 0:
         frames = total_pairs * args.steps
@@ -388,6 +449,18 @@ def main():
                                'note': 'the same %d steps timed again without the per-class HIP events' % args.steps}
         if strong_rec is not None:
             line['strong'] = strong_rec
+        if proj is not None:
+            line['configs3_projection'] = proj
+        line['frames_sha256'] = info.get('frames_sha256')
+        if world > 1:
+            try:
+                rccl = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
+            line['dist'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'rccl_version': rccl,
+                            'rank_ms_per_step_min_max': [min(info['rank_ms_per_step']), max(info['rank_ms_per_step'])],
+                            'gather_ms_unoverlapped': info.get('gather_ms_unoverlapped'),
+                            'gather_bytes_per_rank': info.get('gather_bytes_per_rank')}
         if prof is not None:
             conv = prof['conv3x3']
             ach = conv['flops'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0

@@ -61,8 +61,10 @@ class TorchPath(object):
                 x = F.interpolate(x, scale_factor=2, mode='nearest')
         return x
 
-    def stylize(self, content, style, relu_targets, alpha=1.0, wct_mode='tf', timers=None):
-        """timers (optional dict): receives 'transform_s', the seconds spent in the NumPy transforms of this call"""
+    def stylize(self, content, style, relu_targets, alpha=1.0, wct_mode='tf', timers=None, transform=None):
+        """timers (optional dict): receives 'transform_s', the seconds spent in the NumPy transforms of this call.
+        transform (optional callable (fc, fs, alpha) -> [1][H][W][C]): used instead of the restatement -- bench.py passes the
+        reference's own lifted function where the reference tree is present"""
         import time
         t_transform = 0.0
         to_t = lambda img: torch.from_numpy(np.float32(preprocess(img)).transpose(2, 0, 1)[None])     # noqa: E731
@@ -76,7 +78,7 @@ class TorchPath(object):
                 fc = to_np(self.encode(x, [relu])[relu])
                 fs = to_np(sfeat[relu])
                 t0 = time.time()
-                t = (wct_oracle.wct_tf if wct_mode == 'tf' else wct_oracle.wct_np)(fc, fs, alpha)
+                t = (transform or (wct_oracle.wct_tf if wct_mode == 'tf' else wct_oracle.wct_np))(fc, fs, alpha)
                 t_transform += time.time() - t0
                 x = self.decode(torch.from_numpy(np.ascontiguousarray(t[0].transpose(2, 0, 1)))[None], relu)
         if timers is not None:

@@ -2,7 +2,7 @@
 parameters the hand-written cases do not enumerate -- every call through the C ABI, checked against the CPU oracle.
 
 What the sweep is after:
-  * WCT: any C in {32..256 step 32}, ragged / tiny pixel counts (N >= 2, N < C included), feature scales from 1e-3
+  * WCT: any C in {32..256 step 32} and C = 512, ragged / tiny pixel counts (N >= 2, N < C included), feature scales from 1e-3
     to 1e3 (the covariance and apply GEMMs split their operands into fp16 hi+lo pairs after a per-matrix
     power-of-two scaling: the result must not depend on the magnitude of the input), both semantics, any alpha;
   * AdaIN: same shapes;
@@ -20,7 +20,7 @@ from wct_tf_amd import _lib  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
-STATS = {'wct_cases': 0, 'wct_near_cutoff': 0, 'wct_indeterminate': 0}
+STATS = {'wct_cases': 0, 'wct_near_cutoff': 0, 'wct_indeterminate': 0, 'wct_wide': 0}
 
 
 @pytest.fixture(scope='module')
@@ -39,12 +39,7 @@ def features(rng, n, c, scale, mix=True):
     return np.float32(g * scale)
 
 
-@settings(max_examples=30, **COMMON)
-@given(c=st.sampled_from([32, 64, 96, 128, 160, 256]), hc=st.integers(2, 26), wc=st.integers(2, 26),
-       hs=st.integers(2, 26), ws=st.integers(2, 26),
-       alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['np', 'tf']), log_scale=st.floats(-3.0, 3.0),
-       seed=st.integers(0, 2 ** 31 - 1))
-def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
+def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     rng = np.random.default_rng(seed)
     scale = 10.0 ** log_scale
     nc, ns = hc * wc, hs * ws
@@ -72,7 +67,7 @@ def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_s
     STATS['wct_near_cutoff'] += 1
     shaped = (fc.reshape(1, hc, wc, c), fs.reshape(1, hs, ws, c))
     # kept counts inside the band: all of them when the band is narrow, its ends and their neighbours when it is wide
-    if (ranges[0][1] - ranges[0][0] + 1) * (ranges[1][1] - ranges[1][0] + 1) <= 200:
+    if (ranges[0][1] - ranges[0][0] + 1) * (ranges[1][1] - ranges[1][0] + 1) <= (200 if c < 512 else 16):   # (two SVDs per candidate)
         cand = [list(range(r[0], r[1] + 1)) for r in ranges]
     else:
         cand = [sorted({r[0], min(r[0] + 1, r[1]), max(r[1] - 1, r[0]), r[1]}) for r in ranges]
@@ -93,19 +88,56 @@ def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_s
     # more noise eigenvalues the two draws have been measured up to ~10x `own` apart (C = 96..256, N = 4: 1.0e-3 .. 2.4e-3
     # with own 1e-4 .. 2e-4) -- the tolerance there is 2e-3 or 8x own; narrow bands keep 1e-3 or 4x own
     wide = max(r[1] - r[0] for r in ranges) >= 8
-    tol = max(2e-3, 8 * own) if wide else max(1e-3, 4 * own)
     STATS['wct_indeterminate'] += own > 2.5e-4
     print('near cut-off: C=%d N=%d/%d scale 1e%.1f kept-count band %s: best rel %.2e (reference fp32 vs fp64 on this input: %.2e)'
           % (c, nc, ns, log_scale, ranges, min(errs.values()), own))
-    assert min(errs.values()) < tol, (c, nc, ns, alpha, mode, log_scale, min(errs.values()), own)
+    if not wide:
+        assert min(errs.values()) < max(1e-3, 4 * own), (c, nc, ns, alpha, mode, log_scale, min(errs.values()), own)
+        return
+    # WIDE band -- the A-B the advisor asked for (r3) and the review repeated (r4): is the distance above the reference's
+    # rounding noise, or this path's own error (the second-order completion of the spectral functions)?  Both fp32 evaluations
+    # are measured against the EXACT answer: the oracle in float64 at every kept count of the band.  `ref_noise` = how far the
+    # reference's own float32 arithmetic lands from the nearest exact outcome; `gpu_exact` = the same for this path.  The stated
+    # budget holds against the exact answer -- 1e-3, or 4x what the reference's arithmetic itself loses on this input.
+    STATS['wct_wide'] += 1
+    sh64 = (np.float64(shaped[0]), np.float64(shaped[1]))
+    kw64 = {'dtype': np.float64} if mode == 'tf' else {}
+    exact = {k: np.asarray(fn(*sh64, alpha, keep=k, **kw64)).reshape(nc, c) for k in errs}
+    gpu_exact = min(rel_err(got, e) for e in exact.values())
+    ref_noise = min(rel_err(o32, e) for e in exact.values())
+    print('   wide band: vs the exact (float64) outcomes of the band: this path %.2e, the reference in float32 %.2e'
+          % (gpu_exact, ref_noise))
+    assert gpu_exact < max(1e-3, 4 * ref_noise), (c, nc, ns, alpha, mode, log_scale, gpu_exact, ref_noise)
+
+
+@settings(max_examples=30, **COMMON)
+@given(c=st.sampled_from([32, 64, 96, 128, 160, 256]), hc=st.integers(2, 26), wc=st.integers(2, 26),
+       hs=st.integers(2, 26), ws=st.integers(2, 26),
+       alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['np', 'tf']), log_scale=st.floats(-3.0, 3.0),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
+    _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed)
+
+
+@settings(max_examples=6, **COMMON)
+@given(hc=st.integers(2, 40), wc=st.integers(2, 40), hs=st.integers(2, 40), ws=st.integers(2, 40),
+       alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['np', 'tf']), log_scale=st.floats(-3.0, 3.0),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_wct_random_shapes_and_scales_512_channels(ctx, hc, wc, hs, ws, alpha, mode, log_scale, seed):
+    """the same sweep at C = 512, the channel count of two of the five levels (relu4_1, relu5_1): pixel counts from 4 to
+    1600 on either side of C, so full-rank and rank-deficient covariances both occur"""
+    _wct_case(ctx, 512, hc, wc, hs, ws, alpha, mode, log_scale, seed)
+
+
 
 
 def test_wct_random_shapes_report():
     """Runs after the sweep above: how many of its cases had an eigenvalue inside the noise band of the cut-off
     (those were checked against the band of legitimate outcomes instead of being skipped)."""
     print('WCT sweep: %(wct_cases)d cases, %(wct_near_cutoff)d with an eigenvalue within fp32 noise of the 1e-5 cut-off, '
-          '%(wct_indeterminate)d of those with a reference output that is itself rounding noise above 2.5e-4' % STATS)
-    assert STATS['wct_cases'] >= 30
+          '%(wct_indeterminate)d of those with a reference output that is itself rounding noise above 2.5e-4, %(wct_wide)d with a band '
+          'of eight or more noise eigenvalues (judged against the float64 outcomes)' % STATS)
+    assert STATS['wct_cases'] >= 36
 
 
 @settings(max_examples=15, **COMMON)

@@ -156,6 +156,34 @@ def test_config2_single_level_relu3_512_end_to_end(ctx, weights):
         assert psnr(got, want) > min_psnr and d.max() <= max_lsb
 
 
+def test_config1_single_level_relu1_256_alpha1_np_end_to_end(ctx, weights):
+    """BASELINE config 1 AS STATED, through the GPU path: single level relu1_1, 256x256 content and style, alpha = 1.0, the
+    NumPy `wct()` semantics (ops.py:92-140: eps inside the gains, content mean not restored) -- one conv1_1 encoder pass,
+    one 64-channel transform over 65 536 pixels, the one-conv relu1_1 decoder (model.py:123-176, 255-298) and
+    wct.py:60-68 at the ends.  The final uint8 frame against oracle.stylize(wct_mode='np') in fp32 (the reference's
+    arithmetic) and with this path's fp16 storage; the fused call must also be the chained ops, bit for bit."""
+    from wct_tf_amd import _lib
+    targets = ['relu1_1']
+    c = synthetic_image(1000, 256, 256)
+    s = synthetic_image(2000, 256, 256)
+    _teacher_forced(ctx, weights, c, s, targets, 1.0, 'np')
+    got = ctx.stylize(c, s, targets, alpha=1.0, wct_mode='np')
+    fc, fs = ctx.encode(np.float32(c / 255.), 'relu1_1'), ctx.encode(np.float32(s / 255.), 'relu1_1')
+    t = ctx.transform(fc.reshape(-1, 64), fs.reshape(-1, 64), 1.0, _lib.WCT_NP).reshape(fc.shape)
+    assert np.array_equal(got, np.uint8(np.clip(ctx.decode(t, 'relu1_1'), 0, 1) * 255))
+    want_tf = oracle.stylize(c, s, weights, targets, alpha=1.0, wct_mode='tf')
+    for name, want, min_psnr, max_lsb in (
+            # measured on MI355X (round 5): see profiles/r05_parity_holes.txt
+            ('fp32 oracle', oracle.stylize(c, s, weights, targets, alpha=1.0, wct_mode='np'), 45.0, 4),
+            ('fp16-storage oracle', oracle.stylize(c, s, weights, targets, alpha=1.0, wct_mode='np', fp16_storage=True), 50.0, 2)):
+        d = np.abs(got.astype(int) - want.astype(int))
+        print('config 1 vs %s: psnr %.1f dB, max LSB %d, mean LSB %.4f, pixels off by > 1 LSB %.5f, frame std %.1f'
+              % (name, psnr(got, want), d.max(), d.mean(), (d > 1).mean(), want.std()))
+        assert got.shape == want.shape == (256, 256, 3) and want.std() > 10
+        assert psnr(got, want) > min_psnr and d.max() <= max_lsb
+    print('config 1: np-mode frame vs the tf-mode oracle %.1f dB (the two semantics differ)' % psnr(got, want_tf))
+
+
 def test_config3_five_levels_512_end_to_end_on_a_well_conditioned_net():
     """BASELINE config 3 END TO END: full relu5_1 -> relu1_1 chain, 512x512 content and style, alpha 0.8, the final uint8
     frame against oracle.stylize (model.py:78-94: every level encodes clip(previous decoded), wct.py:60-68 at the ends).
@@ -581,6 +609,42 @@ def test_bench_gpus2_self_launches_two_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--size', '64', '--steps', '1', '--warmup', '0',
                           '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and '"n_gpus"' not in out.stdout
+
+
+def test_two_ranks_gathered_frames_equal_the_single_rank_frames_bit_for_bit(ctx, weights):
+    """The N > 1 DEVICE path end to end (VERDICT r4 missing #4): `bench.py --gpus 2 --global-batch 6` at 512x512 -- two ranks
+    (sharing the one GPU of this box, exchange through gloo), each stylizing its contiguous shard of six DISTINCT pairs from
+    device-resident inputs (shard_range -> stylize_batch_dev at the shard's byte offsets) and ONE gather to rank 0 (gather_frames).
+    The digest of the gathered [6][512][512][3] tensor must be the digest of the frames a single rank computes for the same six
+    pairs: `bench.py --gpus 1 --global-batch 6`, and stylize_batch called here directly.  A wrong shard offset, a wrong gather
+    order or a rank reading another rank's inputs changes it."""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    n, size = 6, 512
+    content = np.stack([synthetic_image(1000 + i, size, size) for i in range(n)])
+    style = np.stack([synthetic_image(2000 + i, size, size) for i in range(n)])
+    direct = ctx.stylize_batch(content, style, RELU_TARGETS, alpha=0.8)
+    assert len({hashlib.sha256(f.tobytes()).hexdigest() for f in direct}) == n          # six different frames
+    want = hashlib.sha256(np.ascontiguousarray(direct).tobytes()).hexdigest()
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    digests = {}
+    for gpus in (1, 2):
+        e = dict(env, WCT_BENCH_BACKEND='gloo', WCT_BENCH_SHARE_GPU='1') if gpus > 1 else env
+        out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--size', str(size), '--global-batch', str(n),
+                              '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-latency', '--no-prof'],
+                             env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith('{')][-1])
+        assert line['n_gpus'] == gpus and line['config']['global_batch'] == n and line['scaling'] == 'strong'
+        digests[gpus] = line['frames_sha256']
+        if gpus > 1:
+            assert line['dist']['world_size'] == 2 and line['dist']['backend'] == 'gloo'
+            assert line['dist']['gather_ms_unoverlapped'] > 0 and len(line['dist']['rank_ms_per_step_min_max']) == 2
+    print('frames digest: direct %s, bench --gpus 1 %s, bench --gpus 2 %s' % (want[:16], digests[1][:16], digests[2][:16]))
+    assert digests[1] == want and digests[2] == want
 
 
 def test_swap5_pipeline(ctx, weights):
