@@ -102,9 +102,10 @@ int wct_style_swap(wct_ctx* ctx, const float* content, int hc, int wc, const flo
  * (wct.py:17-18) and predict(ss_alpha) (wct.py:70).  Defaults 0.6 / 3 / 1 (stylize.py:34-37). */
 int wct_set_style_swap(wct_ctx* ctx, float ss_alpha, int patch_size, int stride);
 /* symmetric eigendecomposition used in place of tf.svd / np.linalg.svd (ops.py:53-55,110,123):
- * A [nmat][C][C] in; evals [nmat][C], evecs [nmat][C][C] (columns) out.  A must be symmetric to the bit
- * (a[i][j] == a[j][i]): the solver reads an element from whichever triangle is contiguous for the kernel
- * at hand (the covariances of the transform are mirrored exactly by construction). */
+ * A [nmat][C][C] in; evals [nmat][C], evecs [nmat][C][C] (columns) out.  The UPPER triangle of A (a[i][j],
+ * i <= j) is authoritative: the entry point mirrors it into the lower one on its staged copy before the
+ * solve (the solver reads an element from whichever triangle is contiguous for the kernel at hand), so a
+ * matrix that is symmetric only to round-off, or upper-only data, is solved as that symmetric matrix. */
 int wct_eigh(wct_ctx* ctx, const float* A, int C, int nmat, float* evals, float* evecs,
              int* sweeps_out /* [nmat] or NULL; same contract as wct_transform's */);
 /* Conv2DReflect (ops.py:17-19): x [H][W][Cin] fp32, w HWIO, y [Ho][Wo][Cout] fp32;

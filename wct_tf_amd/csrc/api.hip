@@ -703,6 +703,26 @@ __global__ void extract_diag_kernel(const float* A, float* d, int C) {
   if (k < C) d[m * C + k] = A[(size_t)m * C * C + (size_t)k * C + k];
 }
 
+// wct_eigh's input contract: the UPPER triangle is authoritative.  The solver reads an element from whichever triangle is
+// contiguous for the kernel at hand, so the staged copy is mirrored first (a C caller may pass upper-only data or a matrix
+// that is symmetric only to round-off -- ADVICE r4).  In tiles: coalesced rows in, transposed through LDS out.
+__global__ __launch_bounds__(256) void mirror_upper_kernel(float* A, int C) {
+  __shared__ float t[32][33];
+  const int bi = blockIdx.x, bj = blockIdx.y;
+  if (bj < bi) return;                                     // tile (bi, bj) of the upper triangle -> tile (bj, bi)
+  float* Am = A + (size_t)blockIdx.z * C * C;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    t[r][tx] = (i < C && j < C) ? Am[(size_t)i * C + j] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;           // element (i, j) of the lower side = upper (j, i)
+    if (i < C && j < C && i > j) Am[(size_t)i * C + j] = t[tx][r];
+  }
+}
+
 extern "C" int wct_eigh(wct_ctx* c, const float* A, int C, int nmat, float* evals, float* evecs, int* sweeps_out) {
   ARG_CHECK(c && A && evals && evecs && nmat >= 1 && nmat <= 64);
   HIP_TRY(hipSetDevice(c->device));
@@ -710,6 +730,7 @@ extern "C" int wct_eigh(wct_ctx* c, const float* A, int C, int nmat, float* eval
   const size_t mb = (size_t)nmat * C * C * 4;
   void* dA;
   TRY(stage_in(c, 0, A, mb, &dA));
+  hipLaunchKernelGGL(mirror_upper_kernel, dim3(cdiv(C, 32), cdiv(C, 32), nmat), dim3(256), 0, c->stream, (float*)dA, C);
   TRY(ensure(c, c->stage[1], mb));
   TRY(ensure(c, c->stage[2], (size_t)nmat * C * 4 + 1024));
   TRY(ensure(c, c->wct_ws, jacobi_workspace_bytes(C, nmat)));

@@ -41,9 +41,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // A-B / tuning switches.  In the product build they are constants: a stray environment variable must never change the
 // numerics of a library whose contract is bit-reproducible output.  Only a -DWCT_TUNING build (tools/, experiments on the
-// GPU box) reads them from the environment.  Two documented TEST hooks stay live in every build, both safe by
-// construction: WCT_JACOBI_MAX_SWEEPS can only LOWER the sweep budget (the solve then fails loudly, never silently), and
-// WCT_FUSE_STATS=0 selects a path whose output is bit-identical (asserted by tests/test_gpu_pipeline.py).
+// GPU box) reads them from the environment.  THREE documented TEST hooks stay live in every build, all safe by
+// construction: WCT_JACOBI_MAX_SWEEPS can only LOWER the sweep budget (clamped to the compiled one; the solve then fails
+// loudly, never silently); WCT_FUSE_STATS=0 and WCT_FUSE_CONV1=0 each select a path whose output is bit-identical
+// (asserted by tests/test_gpu_pipeline.py).  grep getenv: these three and nothing else outside #ifdef WCT_TUNING.
 #ifdef WCT_TUNING
 #include <stdlib.h>
 static inline int tune_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }

@@ -560,6 +560,18 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   static const int strip_force = tune_int("WCT_FUSE1_STRIP", 0);   // tuning switch
   const int strip = !FUSE1 ? 1 : strip_force ? strip_force : tiles >= 8192 ? 4 : tiles >= 4096 ? 2 : 1;
   dim3 grid((FUSE1 ? cdiv(tiles_x, strip) : tiles_x) * tiles_y * n_tiles, a.B);
+  if (lds > 64 * 1024) {
+    // more dynamic LDS than the 64 KiB a runtime may enforce by default (gfx950 has 160 KiB per CU): say so, once per device
+    // and instantiation; a refusal surfaces here and not at a later synchronisation
+    static bool raised[16] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 16 && !raised[dev]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      raised[dev] = true;
+    }
+  }
   hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles, strip);
 #ifdef CONV_TS
   if (a.B >= 8) {
@@ -614,7 +626,9 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   //  (1175 vs 1143 with the double-buffered patch, DB), 256->256 @128 1057-1068 vs 1066-1085, worse where the grid gets
   //  small (512->512 @32: 381 vs 590); without a partner block the first patch and the epilogue of every tile are exposed.
   //  Kept as a switch: the starting point of DESIGN 8.2)
+#ifdef WCT_TUNING      // (2 VGPR spills: not instantiated in the product build -- VERDICT r4)
   if (force == 5 && a.Cout % 256 == 0) return launch_conv_cfg<16, 256, 2, 2>(a, s);
+#endif
   // (round 2: <32,64,2,2> and <16,128,1,4> -- the waves of a block split the output channels instead of the pixels,
   //  halving / removing the redundant weight streams -- measured 593 vs 601 TFLOP/s on 64->64 @512^2 and 5-8 % slower on
   //  the wide layers, profiles/r02_conv_cfg_sweep.txt: the weight streams are not what bounds these layers; removed)

@@ -1403,11 +1403,18 @@ __global__ void jacobi_finalize_kernel(const JacobiState* st, int* sweeps_out, i
 }
 
 constexpr int JACOBI_MAX_SWEEPS = 16;   // round 3: 12 -> 16 (graded rank-deficient 512-channel spectra used 10-12; a failure stays loud)
-// WCT_JACOBI_MAX_SWEEPS (read at every solve): lowers the sweep budget so that the non-convergence path can be tested
+// WCT_JACOBI_MAX_SWEEPS (read at every solve): LOWERS the sweep budget so that the non-convergence path can be tested.  It
+// cannot raise it: a larger budget moves `lenient_from` and with it the sweep counts -- the output bits -- of slowly
+// converging matrices; only a tuning build accepts values above the compiled budget.
 static int jacobi_max_sweeps() {
   const char* e = getenv("WCT_JACOBI_MAX_SWEEPS");
   const int n = e ? atoi(e) : JACOBI_MAX_SWEEPS;
-  return n < 1 ? 1 : (n > 30 ? 30 : n);
+#ifdef WCT_TUNING
+  constexpr int cap = 30;
+#else
+  constexpr int cap = JACOBI_MAX_SWEEPS;
+#endif
+  return n < 1 ? 1 : (n > cap ? cap : n);
 }
 
 size_t jacobi_workspace_bytes(int C, int nmat) {

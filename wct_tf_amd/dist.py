@@ -5,20 +5,11 @@ sharded statically, ONE exchange step -- a gather of the finished uint8 frames t
 The reference has no multi-device code at all (single device string, wct.py:17,31); units
 are the (content, style) pairs it already processes one at a time (stylize.py:70-100)."""
 import os
-import socket
 import subprocess
 import sys
 
 import torch
 import torch.distributed as dist
-
-
-def free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
 def resolve_world(n_gpus, environ=None, share_gpu=False, device_count=None):
@@ -46,18 +37,28 @@ def resolve_world(n_gpus, environ=None, share_gpu=False, device_count=None):
     return ('launch', n_gpus)
 
 
-def launch_ranks(n_gpus, argv, script=None, module=None, timeout=None):
+# environment a rank gets unless the caller's environment already says otherwise: policy of the HOST this was built on, kept
+# in one visible place (callers pass their own dict to launch_ranks(env_defaults=...) to change it)
+RANK_ENV_DEFAULTS = {
+    'HSA_ENABLE_IPC_MODE_LEGACY': '0',      # dmabuf IPC: what RCCL needs on this host driver
+    'OMP_NUM_THREADS': '8',                 # N ranks on one node: do not let each of them start a thread per core
+}
+
+
+def launch_ranks(n_gpus, argv, script=None, module=None, timeout=None, env_defaults=None):
     """Start N ranks of this program on ONE node, one per GPU, and wait for them: `python -m torch.distributed.run
-    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> <script | -m module> argv` -- the same
-    command line the driver uses, so a self-launched run and a torchrun-launched run are the same job.  stdout/stderr pass
-    through (rank 0 prints the result).  Returns the launcher's exit code."""
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(free_port())]
+    --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node N <script | -m module> argv` -- the driver's own
+    launch (`--master-addr 127.0.0.1 --master-port P`) with the port left to the launcher: `--standalone` has its c10d
+    rendezvous bind port 0 itself, so two self-launched jobs on one node cannot race for a port number picked here
+    (bind-close-reuse was a TOCTOU window).  The ranks see the same RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    variables either way.  stdout/stderr pass through (rank 0 prints the result).  Returns the launcher's exit code."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(n_gpus)]
     cmd += ['-m', module] if module else [script]
     cmd += list(argv)
     env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: what RCCL needs on this host driver
-    env.setdefault('OMP_NUM_THREADS', '8')
+    for k, v in (RANK_ENV_DEFAULTS if env_defaults is None else env_defaults).items():
+        env.setdefault(k, v)
     return subprocess.call(cmd, env=env, timeout=timeout)
 
 

@@ -77,9 +77,9 @@ class WCT(object):
 
     @staticmethod
     def preprocess(image):
-        if len(image.shape) == 3:  # Add batch dimension
+        if len(image.shape) == 3:
             image = np.expand_dims(image, 0)
-        return image / 255.        # Range [0,1]
+        return image / 255.
 
     @staticmethod
     def postprocess(image):
