@@ -3,7 +3,7 @@ WCT step runs: `rocm-smi` sampled from a side thread.  The fp16 dense peak the r
 assumes the 2.4 GHz boost clock; this records what the chip sustains under these kernels.
 usage: python tools/r03_clocks.py [seconds per leg]"""
 import sys, os, time, threading, subprocess, re, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from wct_tf_amd.context import Context
 from wct_tf_amd import weights as W

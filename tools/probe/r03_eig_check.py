@@ -1,7 +1,7 @@
 """Accuracy + timing of the batched eigensolver (wct_eigh) against LAPACK (float64): eigenvalues, residual of the
 decomposition, orthogonality, sweeps; WCT_JACOBI_FUSED=0/1 selects the round-2 / look-ahead launches."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from wct_tf_amd.context import Context
 

@@ -1,6 +1,6 @@
 """Timing of wct_eigh at a fixed sweep count (WCT_JACOBI_MAX_SWEEPS) for experiments with the WCT_JACOBI_* switches."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from wct_tf_amd.context import Context
 from wct_tf_amd._lib import WCTNotConverged

@@ -2,7 +2,7 @@
 every call timed on its own (prof events of the solver class), the sweeps each matrix took, the residual of the
 decomposition -- to tell a slow call from a call that ran more sweeps."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from wct_tf_amd.context import Context
 from wct_tf_amd._lib import WCTNotConverged

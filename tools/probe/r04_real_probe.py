@@ -1,6 +1,6 @@
 """Round 4 probe: the real-image leg of bench.py with the class breakdown, profiling events on / off."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from wct_tf_amd.context import Context
 from wct_tf_amd.weights import synthetic_weights, RELU_TARGETS

@@ -243,6 +243,7 @@ struct JacobiFusedArgs {
   int first;            // the D part loads its pair problems straight from Pr (nothing is pending on it)
   int with_v;           // the U part also updates V (otherwise jacobi_vstrip_kernel applies the segment's rotations later)
   int dbg;              // timing experiments (WCT_JACOBI_DBG): 1 U blocks exit at once, 2 D blocks exit at once, 4 no rotation sets
+  int mat_major;        // pair-problem blocks are numbered matrix-fastest (XCD locality; jacobi_fused4_kernel)
 };
 
 // Rotation matrices are stored in FRAGMENT order (the A operand of v_mfma_f32_16x16x4_f32 for V Q, see
@@ -358,6 +359,15 @@ template <int LAY> struct Xchg {
 // (per set on one wave they cost that wave ~310 cycles of every set: three transcendentals and their selects --
 // profiles/r04_jacobi_ts.txt -- and made it the pole of the block).
 constexpr int SX_LOG_B = 32 * 32 * 16;
+// Round 5: pitch of the S image of a cross step, and of the Q image the epilogue reads, in floats.  With the natural pitch
+// of 64 a strip lane's gather simg[k * 64 + l] and scatter put the 32 lanes of a half-wave (k = 0..31, one l each) on ONE
+// bank -- 32-way conflicts on every one of the 20 loads and 40 stores per lane, ~12 k LDS cycles per pair problem (PMC round
+// 4: LDS array 32 % busy, 36 % of it conflicts).  At pitch 68 the bank of (k, l = k + d + 1) is 5 k + d + 1 mod 64: distinct
+// over a half-wave; rows stay 16-byte aligned for the float4 copies of the prologue and the epilogue.  The Q image is kept
+// TRANSPOSED (QT[c * 68 + r] = Q[r][c]): the strips store it with consecutive lanes on consecutive words, and the epilogue's
+// fragment units -- four consecutive ROWS of one column -- are 16-byte loads (they were 12 scalar loads per unit).
+constexpr int SP = 68;
+constexpr int SIMG_F = 64 * SP;            // floats of one padded 64 x 64 image
 
 // dynamic LDS of one launch of the 256-thread kernel (every block of a launch gets the same amount: the larger of its D and
 // U parts).  Kept beside the device code because the CPU emulation (tests/emul) runs the blocks inside EXACTLY this many
@@ -369,8 +379,8 @@ constexpr size_t lds_bytes(int has_d, int has_u, int first, int step_d) {
   if (has_d) {
     if (step_d < 0) need = 2 * M2 * (M2 + 1) * 2 * F + 4 * M2 * F;                     // intra sets: two {S, Q} images, D, O, dummy
     else {
-      need = M2 * M2 * F + Xchg<LAY>::BYTES;                                           // S image, exchange area
-      if (need < 2 * M2 * M2 * F) need = 2 * M2 * M2 * F;                              // S and Q images of the epilogue
+      need = SIMG_F * F + Xchg<LAY>::BYTES;                                            // S image (pitch SP), exchange area
+      if (need < 2 * SIMG_F * F) need = 2 * SIMG_F * F;                                // S and Q images of the epilogue
       (void)first;                                                                     // (look-ahead: W sits in the exchange area)
     }
   }
@@ -379,7 +389,14 @@ constexpr size_t lds_bytes(int has_d, int has_u, int first, int step_d) {
   return need;
 }
 
-template <int W> struct Strip { f32x2 Xpp[W], Xpq[W], Xqp[W], Xqq[W]; };    // {S, Q} pairs; Xpq / Xqq are PHYSICAL slots
+// A lane's cells: S and Q halves in SEPARATE scalar registers (round 5).  Until round 4 they travelled as float2 {S, Q} pairs so
+// that the column rotation was packed arithmetic; a v_pk_fma_f32 costs what two v_fma_f32 cost, and because the S halves of a
+// pair are replaced by the rim exchange at every set while the Q halves stay, the pairs had to be re-assembled with 18-22 v_mov
+// per set (ISA of round 4: 38 v_pk_fma + 2 v_fma + 22 v_mov per lane and set; now 60 v_fma and no moves).  Spq / Sqq / Qpq / Qqq
+// are PHYSICAL slots (cell j uses slot (j + s) mod W in set s).
+// (eight separate arrays behind references: as members of one struct they are one stack object, and hipcc kept a slice of it --
+//  Spq and the head of Sqp -- in scratch memory)
+template <int W> struct Strip { float (&Spp)[W], (&Spq)[W], (&Sqp)[W], (&Sqq)[W], (&Qpp)[W], (&Qpq)[W], (&Qqp)[W], (&Qqq)[W]; };
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The physical-slot arrays of a strip
 // are indexed with (j + s) mod W; written as `#pragma unroll` loops those indices are variables until the unroller has run,
@@ -426,7 +443,7 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
   float rp = 1.f, rq = 1.f;                                            // rho of p_k / of the q currently paired with it
   if (PWAVE) {
     __builtin_amdgcn_s_setprio(2);                                     // the chain of a set runs through this wave
-    ppk = simg[k * 64 + k]; qqk = simg[(32 + k) * 64 + 32 + k]; pqk = simg[k * 64 + 32 + k];   // set 0 pairs k with 32 + k
+    ppk = simg[k * SP + k]; qqk = simg[(32 + k) * SP + 32 + k]; pqk = simg[k * SP + 32 + k];   // set 0 pairs k with 32 + k
     float off, sig;
     jacobi_rotation(ppk, qqk, pqk, floor_m, cpk, spk, off, sig);
     if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
@@ -447,15 +464,20 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
         const float pl = *reinterpret_cast<const float*>(b + L::E + 1024 + dl * 4);
         static_for<W>([&](auto J) {
           constexpr int j = decltype(J)::value;
-          R.Xqq[(j + S) % W][0] = j < 4 ? q4[j < 4 ? j : 0] : q5;
-          R.Xqp[j][0] = j == 0 ? pl : p4[j > 0 ? j - 1 : 0];
+          // (opaque: four consecutive array elements assigned from one float4 are fused into a 16-byte store, which keeps the
+          //  whole array in scratch memory)
+          float vq = j < 4 ? q4[j < 4 ? j : 0] : q5, vp = j == 0 ? pl : p4[j > 0 ? j - 1 : 0];
+          R4_OPAQUE(vq); R4_OPAQUE(vp);
+          R.Sqq[(j + S) % W] = vq;
+          R.Sqp[j] = vp;
         });
       } else {
-        R.Xqq[0][0] = *reinterpret_cast<const float*>(b + L::E + dn * 4);
-        R.Xqp[0][0] = *reinterpret_cast<const float*>(b + L::E + 1024 + dl * 4);
+        R.Sqq[0] = *reinterpret_cast<const float*>(b + L::E + dn * 4);
+        R.Sqp[0] = *reinterpret_cast<const float*>(b + L::E + 1024 + dl * 4);
       }
-      R.Xpq[LASTP] = *reinterpret_cast<const f32x2*>(b + L::PQ + rt * 8);
-      R.Xqq[LASTP][1] = *reinterpret_cast<const float*>(b + L::E + 2048 + rt * 4);
+      const f32x2 pqin = *reinterpret_cast<const f32x2*>(b + L::PQ + rt * 8);
+      R.Spq[LASTP] = pqin[0]; R.Qpq[LASTP] = pqin[1];
+      R.Qqq[LASTP] = *reinterpret_cast<const float*>(b + L::E + 2048 + rt * 4);
     } else {
       const float pl = *reinterpret_cast<const float*>(b + L::B + dl * 16 + (wprev - 1) * 4);
       if constexpr (W > 1) {
@@ -463,18 +485,18 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + L::B + dn * 16);
         static_for<W>([&](auto J) {
           constexpr int j = decltype(J)::value;
-          R.Xqq[(j + S) % W][0] = a4[j];
-          R.Xqp[j][0] = j == 0 ? pl : b4[j > 0 ? j - 1 : 0];
+          float vq = a4[j], vp = j == 0 ? pl : b4[j > 0 ? j - 1 : 0];
+          R4_OPAQUE(vq); R4_OPAQUE(vp);
+          R.Sqq[(j + S) % W] = vq;
+          R.Sqp[j] = vp;
         });
       } else {
-        R.Xqq[0][0] = *reinterpret_cast<const float*>(b + L::A + dn * 16);
-        R.Xqp[0][0] = pl;
+        R.Sqq[0] = *reinterpret_cast<const float*>(b + L::A + dn * 16);
+        R.Sqp[0] = pl;
       }
-      f32x2 pqin;
-      pqin[0] = *reinterpret_cast<const float*>(b + L::B + rt * 16 + 12);
-      pqin[1] = *reinterpret_cast<const float*>(b + L::C + rt * 4);
-      R.Xpq[LASTP] = pqin;
-      R.Xqq[LASTP][1] = *reinterpret_cast<const float*>(b + L::A + rt * 16 + 12);
+      R.Spq[LASTP] = *reinterpret_cast<const float*>(b + L::B + rt * 16 + 12);
+      R.Qpq[LASTP] = *reinterpret_cast<const float*>(b + L::C + rt * 4);
+      R.Qqq[LASTP] = *reinterpret_cast<const float*>(b + L::A + rt * 16 + 12);
     }
   };
 
@@ -496,15 +518,15 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
     static_for<W>([&](auto J) {
       constexpr int j = decltype(J)::value, P = (j + S) % W;
       const float al = rl[j][0], bl = rl[j][1];
-      // columns (pair l) on the {S, Q} pairs as packed arithmetic, then rows (pair k) on the S halves: four packed and four
-      // scalar fma per cell
-      const f32x2 yp = R.Xpp[j] - al * R.Xpq[P], yq = R.Xpq[P] + bl * R.Xpp[j];
-      const f32x2 yqp = R.Xqp[j] - al * R.Xqq[P], yqq = R.Xqq[P] + bl * R.Xqp[j];
-      f32x2 npp = yp, npq = yq;
-      npp[0] = yp[0] - ak * yqp[0];  npq[0] = yq[0] - ak * yqq[0];
-      nqp[j] = yqp[0] + bk * yp[0];  nqq[j] = yqq[0] + bk * yq[0];
-      R.Xpp[j] = npp;  R.Xpq[P] = npq;
-      R.Xqp[j][1] = yqp[1];  R.Xqq[P][1] = yqq[1];
+      // columns (pair l: x <- x - a y, y <- y + b x) on the S rows p_k, q_k and the Q rows k, 32 + k, then rows (pair k) on the S
+      // values: twelve fma per cell, every one of them scalar (see Strip)
+      const float yp = __builtin_fmaf(-al, R.Spq[P], R.Spp[j]), yq = __builtin_fmaf(bl, R.Spp[j], R.Spq[P]);
+      const float yqp = __builtin_fmaf(-al, R.Sqq[P], R.Sqp[j]), yqq = __builtin_fmaf(bl, R.Sqp[j], R.Sqq[P]);
+      const float gp = __builtin_fmaf(-al, R.Qpq[P], R.Qpp[j]), gq = __builtin_fmaf(bl, R.Qpp[j], R.Qpq[P]);
+      const float hp = __builtin_fmaf(-al, R.Qqq[P], R.Qqp[j]), hq = __builtin_fmaf(bl, R.Qqp[j], R.Qqq[P]);
+      R.Spp[j] = __builtin_fmaf(-ak, yqp, yp);  R.Spq[P] = __builtin_fmaf(-ak, yqq, yq);
+      nqp[j] = __builtin_fmaf(bk, yp, yqp);     nqq[j] = __builtin_fmaf(bk, yq, yqq);
+      R.Qpp[j] = gp;  R.Qpq[P] = gq;  R.Qqp[j] = hp;  R.Qqq[P] = hq;
     });
     constexpr int P0 = S % W;                                          // physical pair of column 0
     if (PWAVE) {
@@ -527,7 +549,7 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
       rq = __builtin_bit_cast(float, k == 31 ? firstr : shr);
       // (the ratios of the scales do not wait for the pivot element)
       const float rqp = rq * __builtin_amdgcn_rcpf(rp), rpq = rp * __builtin_amdgcn_rcpf(rq), rpr = rp * rq;
-      ppk = ppn; qqk = nb; pqk = rpr * R.Xpq[P0][0];
+      ppk = ppn; qqk = nb; pqk = rpr * R.Spq[P0];
       float tt;
       const bool rot = jacobi_rotation_cst(ppk, qqk, pqk, cpk, spk, tt);
       f32x2 r; r[0] = tt * rqp; r[1] = tt * rpq;
@@ -543,13 +565,10 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
       }
       *reinterpret_cast<float*>(b + L::E + t * 4) = nqq[W - 1];
       *reinterpret_cast<float*>(b + L::E + 1024 + t * 4) = nqp[W - 1];
-      *reinterpret_cast<f32x2*>(b + L::PQ + t * 8) = R.Xpq[P0];
-      *reinterpret_cast<float*>(b + L::E + 2048 + t * 4) = R.Xqq[P0][1];
+      *reinterpret_cast<f32x2*>(b + L::PQ + t * 8) = f32x2{R.Spq[P0], R.Qpq[P0]};
+      *reinterpret_cast<float*>(b + L::E + 2048 + t * 4) = R.Qqq[P0];
     } else {
-      // (the pairs are taken out as WHOLE values first: element reads of R.Xpq[P0] next to the float4 being assembled were
-      //  widened into one 16-byte load over two array elements, which kept the whole array in scratch memory)
-      const f32x2 pq0 = R.Xpq[P0], qq0 = R.Xqq[P0];
-      float e0 = pq0[0], e1 = pq0[1], e2 = qq0[1];
+      float e0 = R.Spq[P0], e1 = R.Qpq[P0], e2 = R.Qqq[P0];
       R4_OPAQUE(e0); R4_OPAQUE(e1); R4_OPAQUE(e2);
       *reinterpret_cast<f32x4*>(b + L::A + t * 16) = f32x4{nqq[0], W > 1 ? nqq[W > 1 ? 1 : 0] : 0.f, W > 2 ? nqq[W > 2 ? 2 : 0] : 0.f, e2};
       *reinterpret_cast<f32x4*>(b + L::B + t * 16) = f32x4{nqp[0], W > 1 ? nqp[W > 1 ? 1 : 0] : 0.f, W > 2 ? nqp[W > 2 ? 2 : 0] : 0.f, e0};
@@ -590,17 +609,19 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
 // gather -> sets -> scatter for the lanes of one wave (strip width W); contains the barriers of the set loop and one more
 template <int LAY, int W, bool PWAVE>
 __device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned char* xb, int t, float floor_m, float& my_off, float& my_sig) {
-  constexpr int M2 = 64, B = 32;
+  constexpr int B = 32;
   const int k = t & 31, sg = t >> 5;
-  Strip<W> R;
+  float Spp[W], Spq[W], Sqp[W], Sqq[W], Qpp[W], Qpq[W], Qqp[W], Qqq[W];
+  Strip<W> R{Spp, Spq, Sqp, Sqq, Qpp, Qpq, Qqp, Qqq};
   int la[W];
   static_for<W>([&](auto J) {
     constexpr int j = decltype(J)::value;
     const int l = (k + Lay<LAY>::d0(sg) + j + 1) & 31;
     la[j] = l;
     const float one = k == l ? 1.f : 0.f;
-    R.Xpp[j] = f32x2{simg[k * M2 + l], one};        R.Xpq[j] = f32x2{simg[k * M2 + B + l], 0.f};
-    R.Xqp[j] = f32x2{simg[(B + k) * M2 + l], 0.f};  R.Xqq[j] = f32x2{simg[(B + k) * M2 + B + l], one};
+    R.Spp[j] = simg[k * SP + l];        R.Spq[j] = simg[k * SP + B + l];
+    R.Sqp[j] = simg[(B + k) * SP + l];  R.Sqq[j] = simg[(B + k) * SP + B + l];
+    R.Qpp[j] = one;  R.Qpq[j] = 0.f;  R.Qqp[j] = 0.f;  R.Qqq[j] = one;
   });
   strip_sets<LAY, W, PWAVE>(R, xb, simg, t, floor_m, my_off, my_sig);
   __syncthreads();                                  // every lane has taken its last rim: the exchange area becomes the Q image
@@ -612,10 +633,11 @@ __device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned ch
     constexpr int j = decltype(J)::value, P = (j + SF) % W;
     const int l = la[j];
     const float rlp = rho[l], rlq = rho[B + l];
-    simg[k * M2 + l] = (rkp * rlp) * R.Xpp[j][0];        simg[k * M2 + B + l] = (rkp * rlq) * R.Xpq[P][0];
-    simg[(B + k) * M2 + l] = (rkq * rlp) * R.Xqp[j][0];  simg[(B + k) * M2 + B + l] = (rkq * rlq) * R.Xqq[P][0];
-    qimg[k * M2 + l] = rlp * R.Xpp[j][1];        qimg[k * M2 + B + l] = rlq * R.Xpq[P][1];
-    qimg[(B + k) * M2 + l] = rlp * R.Xqp[j][1];  qimg[(B + k) * M2 + B + l] = rlq * R.Xqq[P][1];
+    simg[k * SP + l] = (rkp * rlp) * R.Spp[j];        simg[k * SP + B + l] = (rkp * rlq) * R.Spq[P];
+    simg[(B + k) * SP + l] = (rkq * rlp) * R.Sqp[j];  simg[(B + k) * SP + B + l] = (rkq * rlq) * R.Sqq[P];
+    // Q transposed: QT[column][row]
+    qimg[l * SP + k] = rlp * R.Qpp[j];        qimg[(B + l) * SP + k] = rlq * R.Qpq[P];
+    qimg[l * SP + B + k] = rlp * R.Qqp[j];    qimg[(B + l) * SP + B + k] = rlq * R.Qqq[P];
   });
 }
 
@@ -647,7 +669,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       const float v = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
       finite &= fabsf(v) <= 3.0e38f;
       if (r == c) my_dm = fmaxf(my_dm, fabsf(v));
-      if (p.step_d >= 0) Simg[e] = v;
+      if (p.step_d >= 0) Simg[r * SP + c] = v;
       else { f32x2 w; w[0] = v; w[1] = r == c ? 1.f : 0.f; SQ[r * (M2 + 1) + c] = w; }
     }
     __syncthreads();
@@ -677,7 +699,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     // idle exchange area): one barrier instead of three, no staging of X / Q1 / Q2.
     constexpr int NJ = (B / 16) * NW / NWAVES, P4 = M2 + 4;
     static_assert(NW % NJ == 0, "the jobs of a wave lie in one tile row of W");
-    float* Ws = jsm + FR;                           // [B][P4]
+    float* Ws = jsm + SIMG_F;                       // [B][P4]
     const int li = lane & 15, lq = lane >> 4;
     const int trw = (wave * NJ) / NW;               // tile row of this wave's W jobs
     const int trc = wave / (B / 16), tcc = wave % (B / 16);      // its crit tile (waves 0..3)
@@ -734,7 +756,7 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     for (int i = 0; i < FR / NT; ++i) {
       const int e = tid + i * NT, r = e / M2, c = e % M2;
       if ((r < B) == (c < B) || same) {
-        Simg[e] = sv[i];
+        Simg[r * SP + c] = sv[i];
         finite &= fabsf(sv[i]) <= 3.0e38f;
         if (r == c) my_dm = fmaxf(my_dm, fabsf(sv[i]));
       }
@@ -744,19 +766,19 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * tr + 4 * lq + r, col = B + 16 * tc + li;
-        Simg[row * M2 + col] = crit[r];
-        Simg[col * M2 + row] = crit[r];
+        Simg[row * SP + col] = crit[r];
+        Simg[col * SP + row] = crit[r];
         finite &= fabsf(crit[r]) <= 3.0e38f;
       }
     }
     __syncthreads();
   }
-  float* Qimg = jsm + FR;                           // [M2][M2] floats (cross steps: epilogue only)
+  float* Qimg = jsm + SIMG_F;                       // [M2][SP] floats, TRANSPOSED (cross steps: epilogue only)
   JTS(4);
   if (p.step_d >= 0) {
     {
       // ---- strips: gather, 32 sets, scatter, by wave (the branches execute the same barriers)
-      unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + FR);
+      unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + SIMG_F);
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
       if (wv == 0) strip_wave<LAY, 1, true>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
       else if (LAY == 0) strip_wave<LAY, 5, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
@@ -769,18 +791,16 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
 #pragma unroll
     for (int i = 0; i < FR / 4 / NT; ++i) {
       const int f = tid + i * NT;
-      *reinterpret_cast<f32x4*>(So + (size_t)f * 4) = *reinterpret_cast<const f32x4*>(Simg + f * 4);
+      *reinterpret_cast<f32x4*>(So + (size_t)f * 4) = *reinterpret_cast<const f32x4*>(Simg + (f >> 4) * SP + (f & 15) * 4);
       int qr, qc;
-      qfrag_rc<M2>(f, qr, qc);                      // fragment order (see qfrag_rc)
-      f32x4 q;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = Qimg[(qr + j) * M2 + qc];
-      *reinterpret_cast<f32x4*>(Qo + (size_t)f * 4) = q;
-      // fp16 hi / lo fragment unit f
+      qfrag_rc<M2>(f, qr, qc);                      // fragment order (see qfrag_rc): rows qr .. qr + 3 of column qc
+      *reinterpret_cast<f32x4*>(Qo + (size_t)f * 4) = *reinterpret_cast<const f32x4*>(Qimg + qc * SP + qr);
+      // fp16 hi / lo fragment unit f: rows qfrag16_k(cc, g, 0..3) and (.., 4..7) are two runs of four consecutive rows
       const int l16 = f & 63, part = (f >> 6) & 1, cc = (f >> 7) % NCH, mt = (f >> 7) / NCH;
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = Qimg[qfrag16_k<M2>(cc, l16 >> 4, j) * M2 + 16 * mt + (l16 & 15)];
+      const float* qcol = Qimg + (16 * mt + (l16 & 15)) * SP;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(qcol + qfrag16_k<M2>(cc, l16 >> 4, 0));
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(qcol + qfrag16_k<M2>(cc, l16 >> 4, 4));
+      const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
       half8 hi, lo;
       split_f16x8(x, hi, lo);
       *reinterpret_cast<half8*>(Qo16 + (size_t)f * 8) = part ? lo : hi;

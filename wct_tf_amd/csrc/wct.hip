@@ -1007,7 +1007,9 @@ __global__ __launch_bounds__(r4::Lay<LAY>::NTD, 4) void jacobi_fused4_kernel(Jac
   const int n_d = p.has_d ? p.nmat * npair : 0;
   int b = blockIdx.x;
   if (b < n_d) {
-    const int m = b / npair, g = b % npair;
+    // (p.mat_major: matrix index fastest, like the update tasks behind them -- with a multiple of 8 matrices every block that
+    //  touches matrix m, in this launch and the next, runs on XCD m % 8 and finds the images, logs and tiles in its L2)
+    const int m = p.mat_major ? b % p.nmat : b / npair, g = p.mat_major ? b / p.nmat : b % npair;
     JTS(0);
     if (JDBG(p) & 2) return;                 // (tuning builds, timing experiment: the pair problems exit at once -- results invalid)
     r4::fused_d<M2, LAY>(p, m, g, jsm);
@@ -1041,6 +1043,7 @@ struct VStripArgs {
   const JacobiState* st;
   int C, nmat, step_begin, step_end, seg;
   int dbg;       // timing experiment (WCT_JACOBI_DBG & 128): return at once
+  int mat_major; // grid (nmat, strips) instead of (strips, nmat): see vstrip_launch
 };
 
 template <int M2, int NBLK, int W>
@@ -1048,11 +1051,11 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
   constexpr int B = M2 / 2, TB = B / 16, NCH = M2 / 32, NPAIR = NBLK / 2, FR = M2 * M2, C = NBLK * B;
   constexpr int NLD = FR / 4 / (W * 64) > 0 ? FR / 4 / (W * 64) : 1;        // float4 per thread and tile
   __shared__ __attribute__((aligned(16))) float qs[2][FR];
-  const int m = blockIdx.y;
+  const int m = p.mat_major ? blockIdx.x : blockIdx.y;
   if (p.st[m].seg_stop <= p.seg || JDBG(p)) return;   // no rotations of this segment belong to the matrix (done before it began)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  const int row0 = (blockIdx.x * W + wave) * 16;
+  const int row0 = ((p.mat_major ? blockIdx.y : blockIdx.x) * W + wave) * 16;
   float* Vm = p.V + (size_t)m * C * C + (size_t)(row0 + li) * C + 4 * lq;
   f32x4 v[NBLK * TB];
   auto block_at = [&](int pos, int step) { return step < 0 ? pos : rr_idx(pos, step, NBLK); };
@@ -1494,6 +1497,8 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
   a.Sr = G.Sb[G.par]; a.Sw = G.Sb[G.par ^ 1];
   a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_d = step_d; a.step_u = step_u;
   a.has_d = has_d; a.has_u = has_u; a.first = first; a.with_v = !G.vstrip;
+  static const int xcd = tune_int("WCT_JACOBI_XCD", 1);
+  a.mat_major = (xcd & 2) && M2 == 64 && G.nmat % 8 == 0;
   static const int dbg = tune_int("WCT_JACOBI_DBG", 0);
   a.dbg = dbg;
   const unsigned grid = (has_d ? G.nmat * npair : 0) + (has_u ? G.nmat * ntask : 0);
@@ -1574,8 +1579,14 @@ static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_
   a.V = G.V; a.Qlog = G.Qlog16[G.lg]; a.st = G.st; a.C = C; a.nmat = G.nmat; a.step_begin = step_begin; a.step_end = step_end; a.seg = G.segs;
   static const int dbg = tune_int("WCT_JACOBI_DBG", 0);
   a.dbg = dbg & 128;
+  // Round 5: blocks are handed to the 8 XCDs round-robin by their linear index.  All the row strips of a matrix stream the SAME
+  // rotation log (1 MB per 512-channel matrix and segment); with the strip index running fastest they sat on 8 different XCDs
+  // and every one of the 8 L2s fetched every log from HBM.  With the MATRIX index running fastest (and a multiple of 8 matrices)
+  // the strips of matrix m all run on XCD m % 8 and share its L2.  WCT_JACOBI_XCD=0 (tuning builds): the old order.
+  static const int xcd = tune_int("WCT_JACOBI_XCD", 1);
+  a.mat_major = xcd && G.nmat % 8 == 0;
 #define VSTRIP_CASE(m2, nb, w) \
-  if (M2 == m2 && nblk == nb) hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), dim3(C / 16 / w, G.nmat), dim3(w * 64), 0, s, a);
+  if (M2 == m2 && nblk == nb) hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), a.mat_major ? dim3(G.nmat, C / 16 / w) : dim3(C / 16 / w, G.nmat), dim3(w * 64), 0, s, a);
   VSTRIP_CASE(64, 16, 4) VSTRIP_CASE(64, 8, 8) VSTRIP_CASE(32, 8, 4) VSTRIP_CASE(32, 4, 4) VSTRIP_CASE(32, 2, 2)
 #undef VSTRIP_CASE
 }
