@@ -166,6 +166,13 @@ struct GemmArgs {
   // batching: blockIdx.z = batch * nsplit + split; strides in elements (0 = shared)
   int nsplit;
   size_t sA, sB, s_sub_m, s_sub_n, s_sub_k, s_scale_k, s_out, s_bias;
+  // round 5 (the transform tail in merged launches over the 2P matrices of a level, batch b = matrix 2 * pair + side):
+  const float* A_odd;     // if set: A of an odd batch b is A_odd + (b >> 1) * sA_odd, that of an even one A + (b >> 1) * sA
+  size_t sA_odd;
+  int skip_shared;        // batches b with skip_style_mat(b, 1) have nothing to do (one style for all pairs: WCT_FLAG_STYLE_SHARED)
+  // blend epilogue (T = Tcs Tw -> M = alpha T + (1 - alpha) I, ops.py:83 folded into the apply matrix): the store carries the
+  // blend and the block merges max |M| into mabs[batch] (bit patterns of non-negative floats; zeroed by an earlier kernel)
+  int blend; float alpha; unsigned* mabs;
 };
 
 int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s);

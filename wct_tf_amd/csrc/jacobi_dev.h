@@ -102,6 +102,29 @@ __device__ __forceinline__ bool jacobi_rotation_cst(float app, float aqq, float 
   s = rot ? r * t : 0.f;
   return rot;
 }
+// Round 5: only tan(theta) -- what the chain of a rotation set waits for.  (c, s) follow from it (jacobi_cs_from_t) and feed
+// nothing but the pivot lane's own closed-form diagonals of the NEXT set, so r4::strip_sets derives them after the barrier,
+// under the latency of that set's first LDS reads, instead of before it with every other wave waiting.
+__device__ __forceinline__ bool jacobi_rotation_t(float app, float aqq, float apq, float& tt) {
+  const float den2 = fabsf(app * aqq);
+  const float aapq = fabsf(apq);
+  const float big = fmaxf(fabsf(app), fabsf(aqq)), small = fminf(fabsf(app), fabsf(aqq));
+  const bool live = (fabsf(app) + fabsf(aqq) > JACOBI_FLOOR) & !((small < JACOBI_FLOOR) & (aapq < 1e-6f * big));
+  const bool rot = live & (aapq * aapq > JACOBI_ROT_TOL * JACOBI_ROT_TOL * den2) & (aapq > 1e-36f);
+  const float tau = 0.5f * (aqq - app);
+  const float h = __builtin_amdgcn_sqrtf(tau * tau + apq * apq);
+  float t = aapq * __builtin_amdgcn_rcpf(rot ? fabsf(tau) + h : 1.f);
+  t = (tau >= 0.f) == (apq >= 0.f) ? t : -t;
+  tt = rot ? t : 0.f;
+  return rot;
+}
+__device__ __forceinline__ void jacobi_cs_from_t(float tt, float& c, float& s) {
+  const float n2 = 1.f + tt * tt;
+  float r = __builtin_amdgcn_rsqf(n2);
+  r = r * (1.5f - 0.5f * n2 * r * r);            // one Newton step: c^2 + s^2 = 1 to fp32 round-off
+  c = tt != 0.f ? r : 1.f;                       // (no rotation: exactly the identity)
+  s = r * tt;
+}
 __device__ __forceinline__ void jacobi_rotation_stats(float app, float aqq, float apq, float floor_m, bool rot, float& off, float& sig) {
   const float den2 = fabsf(app * aqq);
   const float aapq = fabsf(apq);
@@ -413,7 +436,7 @@ __device__ __forceinline__ void run_period(F& body, std::integer_sequence<int, I
   (body(std::integral_constant<int, (Is + 1) % LCM>{}, std::true_type{}), ...);
 }
 
-template <int LAY, int W, bool PWAVE>
+template <int LAY, int W, bool PWAVE, int PRIO = 0>
 __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float* simg, int t, float floor_m, float& my_off, float& my_sig) {
   using L = Lay<LAY>;
   constexpr int LCM = (W % 2) ? 2 * W : W, NS = L::NS, SX_CS = Xchg<LAY>::CS, SX_DUMMY = Xchg<LAY>::DUMMY, SX_BUF = L::BUF;
@@ -439,17 +462,19 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
   // travels with q); they work on TRUE values -- closed-form diagonals, pivot element = rho_p rho_q x stored.  32 cosines
   // >= 2^-1/2 each keep rho within [1.5e-5, 1]; strip_wave multiplies the scales back in when it scatters the cells.
   float ppk = 0.f, qqk = 0.f, pqk = 0.f;                               // pair k's pivot block (pivot lanes), true values
-  float cpk = 1.f, spk = 0.f;                                          // the pair's rotation of the set in progress (pivot lanes)
+  float tpk = 0.f;                                                     // tan of the pair's rotation of the set in progress (pivot lanes)
   float rp = 1.f, rq = 1.f;                                            // rho of p_k / of the q currently paired with it
   if (PWAVE) {
     __builtin_amdgcn_s_setprio(2);                                     // the chain of a set runs through this wave
     ppk = simg[k * SP + k]; qqk = simg[(32 + k) * SP + 32 + k]; pqk = simg[k * SP + 32 + k];   // set 0 pairs k with 32 + k
-    float off, sig;
-    jacobi_rotation(ppk, qqk, pqk, floor_m, cpk, spk, off, sig);
+    float off, sig, c0, s0;
+    jacobi_rotation(ppk, qqk, pqk, floor_m, c0, s0, off, sig);
     if (piv) { my_off = fmaxf(my_off, off); my_sig = fmaxf(my_sig, sig); }
-    const float t0 = spk * __builtin_amdgcn_rcpf(cpk);                 // (no rotation: s = 0)
-    f32x2 r; r[0] = t0; r[1] = t0;
+    tpk = s0 * __builtin_amdgcn_rcpf(c0);                              // (no rotation: s = 0)
+    f32x2 r; r[0] = tpk; r[1] = tpk;
     *reinterpret_cast<f32x2*>(xb + a_csw) = r;
+  } else if (PRIO > 0) {
+    __builtin_amdgcn_s_setprio(PRIO);                                  // (tuning builds: WCT_JACOBI_DBG & 8)
   }
   __syncthreads();                                                     // (the S image is free from here on)
 
@@ -533,7 +558,8 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
       // pair k after this set (closed form from registers, true values); partner diagonal of the next set = the q diagonal pair
       // k + 1 has just produced (lane k + 1 of this half-wave), and with it comes that q's scale; next pivot element = this
       // lane's freshly rotated cell (k, 0), scaled back
-      const float ck = cpk, sk = spk;
+      float ck, sk;
+      jacobi_cs_from_t(tpk, ck, sk);                                   // (of the rotation published BEFORE the last barrier)
       const float c2 = ck * ck, s2 = sk * sk, cs2 = 2.f * ck * sk;
       const float ppn = c2 * ppk - cs2 * pqk + s2 * qqk;
       const float qqn = s2 * ppk + cs2 * pqk + c2 * qqk;
@@ -550,9 +576,8 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
       // (the ratios of the scales do not wait for the pivot element)
       const float rqp = rq * __builtin_amdgcn_rcpf(rp), rpq = rp * __builtin_amdgcn_rcpf(rq), rpr = rp * rq;
       ppk = ppn; qqk = nb; pqk = rpr * R.Spq[P0];
-      float tt;
-      const bool rot = jacobi_rotation_cst(ppk, qqk, pqk, cpk, spk, tt);
-      f32x2 r; r[0] = tt * rqp; r[1] = tt * rpq;
+      const bool rot = jacobi_rotation_t(ppk, qqk, pqk, tpk);
+      f32x2 r; r[0] = tpk * rqp; r[1] = tpk * rpq;
       *reinterpret_cast<f32x2*>(xb + NX * 256 + a_csw) = r;
       *reinterpret_cast<f32x4*>(logw) = f32x4{ppk, qqk, pqk, rot ? 1.f : 0.f};
       logw += log_step;
@@ -585,7 +610,7 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
   for (int it = 0; it < 30 / LCM; ++it) run_period<LCM>(body, std::make_integer_sequence<int, LCM>{});     // sets 1 .. 30
   body(std::integral_constant<int, 31 % LCM>{}, std::true_type{});     // set 31
   take_rim(std::integral_constant<int, 32 % LCM>{});                   // the arrangement of "set 32" = that of set 0
-  if (PWAVE) __builtin_amdgcn_s_setprio(0);
+  if (PWAVE || PRIO > 0) __builtin_amdgcn_s_setprio(0);
   // the scales of the 64 indices for strip_wave's scatter (the (a, b) slots of the buffer nobody reads any more: the last set
   // read the other one, and a barrier lies between)
   if (piv) {
@@ -607,7 +632,7 @@ __device__ __forceinline__ void strip_sets(Strip<W>& R, unsigned char* xb, float
 }
 
 // gather -> sets -> scatter for the lanes of one wave (strip width W); contains the barriers of the set loop and one more
-template <int LAY, int W, bool PWAVE>
+template <int LAY, int W, bool PWAVE, int PRIO = 0>
 __device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned char* xb, int t, float floor_m, float& my_off, float& my_sig) {
   constexpr int B = 32;
   const int k = t & 31, sg = t >> 5;
@@ -623,7 +648,7 @@ __device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned ch
     R.Sqp[j] = simg[(B + k) * SP + l];  R.Sqq[j] = simg[(B + k) * SP + B + l];
     R.Qpp[j] = one;  R.Qpq[j] = 0.f;  R.Qqp[j] = 0.f;  R.Qqq[j] = one;
   });
-  strip_sets<LAY, W, PWAVE>(R, xb, simg, t, floor_m, my_off, my_sig);
+  strip_sets<LAY, W, PWAVE, PRIO>(R, xb, simg, t, floor_m, my_off, my_sig);
   __syncthreads();                                  // every lane has taken its last rim: the exchange area becomes the Q image
   constexpr int LCM = (W % 2) ? 2 * W : W, SF = 32 % LCM;
   // the pending scales of the scaled rotations: S[i][j] = rho_i rho_j x stored, Q[r][j] = rho_j x stored (behind the Q image)
@@ -781,6 +806,9 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       unsigned char* xb = reinterpret_cast<unsigned char*>(jsm + SIMG_F);
       const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
       if (wv == 0) strip_wave<LAY, 1, true>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
+#ifdef WCT_TUNING
+      else if (LAY == 0 && (p.dbg & 8)) strip_wave<LAY, 5, false, 1>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);   // strip waves at priority 1
+#endif
       else if (LAY == 0) strip_wave<LAY, 5, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
       else if (wv == 1) strip_wave<LAY, 3, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
       else strip_wave<LAY, 2, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);

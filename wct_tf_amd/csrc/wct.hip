@@ -115,28 +115,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(StatArgs p) {
 }
 
 // scale[m] = 2^k with 2 * max|x| * 2^k in [8192, 16384): the centred features |x - mean| <= 2 max|x| then
-// sit well inside the fp16 range, whatever the range of the fp32 input (1 if the input is all zero)
-__global__ void cov_scale_kernel(const float* absmax, float* scale, int nslab, int shared_style) {
-  const int mat = blockIdx.x;
-  if (skip_style_mat(mat, shared_style)) return;
-  float m = 0.f;
-  for (int i = threadIdx.x; i < nslab; i += 64) m = fmaxf(m, absmax[(size_t)mat * nslab + i]);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if (threadIdx.x == 0) {
-    float sc = 1.f;
-    if (m > 0.f && m < 1e30f) {
-      int e;
-      frexpf(2.f * m, &e);                   // 2m = f * 2^e, f in [0.5, 1)
-      sc = ldexpf(1.f, 14 - e);
-    }
-    scale[mat] = sc;
-  }
-}
-
-// out[m][c] = sum_slab partial / denom_side
-__global__ void colsum_finish_kernel(const float* partial, float* out, int C, int nslab, float d0, float d1, int shared_style) {
+// sit well inside the fp16 range, whatever the range of the fp32 input (1 if the input is all zero) -- computed by block 0 of
+// colsum_finish_kernel (round 5; it was a launch of its own, cov_scale_kernel)
+// out[m][c] = sum_slab partial / denom_side; with absmax / scale given, block 0 of a matrix also does cov_scale_kernel's job
+// (round 5: one launch less per level)
+__global__ void colsum_finish_kernel(const float* partial, float* out, int C, int nslab, float d0, float d1, int shared_style,
+                                     const float* absmax = nullptr, float* scale = nullptr) {
   const int mat = blockIdx.y;
   if (skip_style_mat(mat, shared_style)) return;
+  if (scale && blockIdx.x == 0 && threadIdx.x < 64) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nslab; i += 64) m = fmaxf(m, absmax[(size_t)mat * nslab + i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) {
+      float sc = 1.f;
+      if (m > 0.f && m < 1e30f) {
+        int e;
+        frexpf(2.f * m, &e);                   // 2m = f * 2^e, f in [0.5, 1)
+        sc = ldexpf(1.f, 14 - e);
+      }
+      scale[mat] = sc;
+    }
+  }
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   // eight independent partial sums keep eight loads in flight (a single dependent chain of up to 256 L2
@@ -219,9 +219,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int batch = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
+  if (p.skip_shared && skip_style_mat(batch, 1)) return;
   const int kbeg = split * p.ksplit;
   const int kend = min(p.K, kbeg + p.ksplit);
-  p.A += batch * p.sA; p.B += batch * p.sB;
+  if (p.A_odd) p.A = (batch & 1) ? p.A_odd + (batch >> 1) * p.sA_odd : p.A + (batch >> 1) * p.sA;
+  else p.A += batch * p.sA;
+  p.B += batch * p.sB;
   if (p.a_sub_m) p.a_sub_m += batch * p.s_sub_m;
   if (p.b_sub_n) p.b_sub_n += batch * p.s_sub_n;
   if (p.a_sub_k) p.a_sub_k += batch * p.s_sub_k;
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   // use in every predicated block, and each of those waits for all stores before it (64 serial round trips per thread)
 #pragma unroll
   for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(biasv[j]));
+  float av = 0.f;                                // blend epilogue: max |M| of this lane's elements
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -291,11 +295,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (gm < p.M && gn < p.N) {
           float v = acc[i][j][r] + bias;
+          if (p.blend) {                         // (uniform) what blend_matrix_kernel did to the stored T, element by element
+            v = p.alpha * acc[i][j][r];
+            if (gm == gn) v += 1.f - p.alpha;
+            av = fmaxf(av, fabsf(v));
+          }
           if (o32) o32[(size_t)gm * p.ldo + gn] = v;
           if (o16) o16[(size_t)gm * p.ldo + gn] = (half_t)v;
         }
       }
     }
+  if (p.blend) {                                 // one atomic per wave; the maximum does not depend on the order
+    for (int o = 32; o > 0; o >>= 1) av = fmaxf(av, __shfl_xor(av, o, 64));
+    if (lane == 0 && av < 1e30f) atomicMax(p.mabs + batch, __float_as_uint(av));
+  }
 }
 
 int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s) {
@@ -325,7 +338,7 @@ int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s) {
 // lo = fp16(v - hi) (the subtraction is exact): 22 significand bits, and hi*hi + hi*lo + lo*hi is
 // accumulated in fp32 by three v_mfma_f32_32x32x16_f16 (the dropped lo*lo term is 2^-22 relative).  That
 // is fp32-product accuracy at 3/16 of the fp32-MFMA time (v_mfma_f32_32x32x2_f32: 64 cycles for K=2).
-// s is a power of two per matrix (cov_scale_kernel) so no fp32 input can leave the fp16 range.
+// s is a power of two per matrix (colsum_finish_kernel) so no fp32 input can leave the fp16 range.
 // Only tiles on or above the diagonal are computed (cov_finish_kernel mirrors); a diagonal tile stages
 // its operand once.  Block = BT x BT tile, 256 threads = 2x2 waves; K-stage = 32 pixels.
 // LDS operand image: [channel][32 k] fp16 = 64-B rows, 16-B pieces XOR-swizzled as in the conv kernel.
@@ -1932,6 +1945,127 @@ __global__ __launch_bounds__(256) void spectral_add2_kernel(const float* A, floa
   }
 }
 
+// ---- round 5: the transform tail in MERGED launches.  Until round 4 every level ran the chain spectral_matrix -> prep2 ->
+// products -> add2 -> V G -> (V G) V^T twice, content side then style side (13 launches), then T = Tcs Tw, a memset, the blend
+// and the apply: 17 launches per level, most of them a few microseconds of work on half the matrices.  Here one launch of each
+// kind covers all 2P matrices of the level (matrix m = 2 pair + side; kind = m & 1: 0 whitening, 1 colouring), the first-order
+// matrix and the second-order operands come out of ONE pass over the tile, the blend rides on the epilogue of T = Tcs Tw
+// (gemm_f32_kernel), and the pass that opens the chain also clears mabs and writes the bias vector: 8 launches per level.
+// Element by element the arithmetic is the one of the kernels above, in the same order: the outputs are the same bits.
+struct SpecAllArgs {
+  const float* A;            // [2P][C][C] rotated covariances (diagonal = eigenvalues, off-diagonal = residual)
+  float* G;                  // [2P][C][C]
+  float *N, *R, *Pm;         // N [2P][C][C]; R, Pm [P][C][C] (whitening side only)
+  const float *X1, *X2;      // add2: X1 [P][C][C], X2 [2P][C][C]
+  int C; float shift; int correct, second, shared_style;
+  unsigned* mabs; const float* mean; float* bias; float alpha; int mode;     // per-pair housekeeping of the opening pass
+};
+
+__global__ __launch_bounds__(256) void spectral_open_all_kernel(SpecAllArgs a) {
+  __shared__ SpectralTile t;
+  const int m = blockIdx.z, p0 = blockIdx.y * 64, q0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int C = a.C, kind = m & 1, pair = m >> 1;
+  const size_t cc = (size_t)C * C;
+  if (kind == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    // what blend_matrix_kernel did besides the blend: bias = alpha ms (+ (1 - alpha) mc in tf mode); and mabs starts at 0
+    if (tid == 0) a.mabs[pair] = 0u;
+    const float* mp = a.mean + (size_t)pair * 2 * C;
+    const float* ms = a.mean + (size_t)(a.shared_style ? 0 : pair) * 2 * C + C;
+    for (int i = tid; i < C; i += 256) {
+      float b = a.alpha * ms[i];
+      if (a.mode == WCT_MODE_TF) b += (1.f - a.alpha) * mp[i];
+      a.bias[pair * C + i] = b;
+    }
+  }
+  if (skip_style_mat(m, a.shared_style)) return;
+  const float* Am = a.A + m * cc;
+  spectral_tile_load(t, Am, C, p0, q0, tid);
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = ty * 4 + i, p = p0 + pl, q = q0 + tx * 4;
+    if (p >= C || q >= C) continue;
+    const f32x4 av = *reinterpret_cast<const f32x4*>(Am + (size_t)p * C + q);
+    const float dp = t.dp[pl];
+    f32x4 g, n4 = {0.f, 0.f, 0.f, 0.f}, r4 = n4, p4 = n4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dk = t.dq[tx * 4 + j];
+      const float em = 0.5f * (av[j] + t.mt[tx * 4 + j][pl]);      // the two triangles agree to round-off; their mean keeps G symmetric
+      g[j] = spectral_entry(dp, dk, a.correct ? em : 0.f, p == q + j, kind, a.shift);
+      if (a.second && p != q + j && dp > 1e-5f && dk > 1e-5f) {
+        const float sp = sqrtf(dp + a.shift), sk = sqrtf(dk + a.shift);
+        n4[j] = em / (sp + sk);
+        r4[j] = em / sk;
+        p4[j] = n4[j] / sk;
+      }
+    }
+    const size_t o = (size_t)p * C + q;
+    *reinterpret_cast<f32x4*>(a.G + m * cc + o) = g;
+    if (a.second) {
+      *reinterpret_cast<f32x4*>(a.N + m * cc + o) = n4;
+      if (kind == 0) { *reinterpret_cast<f32x4*>(a.R + pair * cc + o) = r4; *reinterpret_cast<f32x4*>(a.Pm + pair * cc + o) = p4; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spectral_add2_all_kernel(SpecAllArgs a) {
+  __shared__ float dps[64], dqs[64];
+  __shared__ float x1t[64][65], x2t[64][65];       // mirror tiles of X1 (kind 0 only), X2
+  const int m = blockIdx.z, p0 = blockIdx.y * 64, q0 = blockIdx.x * 64, tid = threadIdx.x;
+  if (skip_style_mat(m, a.shared_style)) return;
+  const int C = a.C, kind = m & 1;
+  const size_t cc = (size_t)C * C;
+  const float* Am = a.A + m * cc;
+  float* Gm = a.G + m * cc;
+  const float* X2 = a.X2 + m * cc;
+  const float* X1 = a.X1 + (size_t)(m >> 1) * cc;
+  int near = 0;                                     // (see spectral_add2_kernel)
+  for (int i = tid; i < C; i += 256) {
+    const float d = fabsf(Am[(size_t)i * C + i]);
+    near |= (d > 3.3e-6f) & (d < 3e-5f);
+  }
+  if (__syncthreads_or(near)) return;
+  if (tid < 64) dps[tid] = p0 + tid < C ? Am[(size_t)(p0 + tid) * C + p0 + tid] : 0.f;
+  else if (tid < 128) dqs[tid - 64] = q0 + tid - 64 < C ? Am[(size_t)(q0 + tid - 64) * C + q0 + tid - 64] : 0.f;
+  const int ty = tid >> 4, tx = tid & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = q0 + ty * 4 + i, c = p0 + tx * 4;
+    f32x4 v1 = {0.f, 0.f, 0.f, 0.f}, v2 = v1;
+    if (r < C && c < C) {
+      v2 = *reinterpret_cast<const f32x4*>(X2 + (size_t)r * C + c);
+      if (kind == 0) v1 = *reinterpret_cast<const f32x4*>(X1 + (size_t)r * C + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x2t[ty * 4 + i][tx * 4 + j] = v2[j]; x1t[ty * 4 + i][tx * 4 + j] = v1[j]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = ty * 4 + i, p = p0 + pl, q = q0 + tx * 4;
+    if (p >= C || q >= C) continue;
+    const size_t o = (size_t)p * C + q;
+    const f32x4 x2 = *reinterpret_cast<const f32x4*>(X2 + o);
+    f32x4 x1 = {0.f, 0.f, 0.f, 0.f};
+    if (kind == 0) x1 = *reinterpret_cast<const f32x4*>(X1 + o);
+    f32x4 g = *reinterpret_cast<const f32x4*>(Gm + o);
+    const float dp = dps[pl];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dq = dqs[tx * 4 + j];
+      if (!(dp > 1e-5f && dq > 1e-5f)) continue;
+      const float sp = sqrtf(dp + a.shift), sq = sqrtf(dq + a.shift);
+      float l2;
+      if (kind == 1) l2 = -0.5f * (x2[j] + x2t[tx * 4 + j][pl]) / (sp + sq);
+      else l2 = (0.5f * (x1[j] + x1t[tx * 4 + j][pl]) + 0.25f * (sp + sq) * (x2[j] + x2t[tx * 4 + j][pl])) / (sp * sq * (sp + sq));
+      g[j] += l2;
+    }
+    *reinterpret_cast<f32x4*>(Gm + o) = g;
+  }
+}
+
 // 0: spectral functions of the diagonal only, 1: + first-order completion, 2 (default): + second-order completion
 static int eig_correct_enabled() {
   static const int on = tune_int("WCT_EIG_CORRECT", 2);
@@ -1981,37 +2115,8 @@ static int launch_spectral_function(const float* A, const float* V, float* G, fl
   return launch_gemm(h, 1, nbatch, s);
 }
 
-// M = alpha T + (1-alpha) I ; bias = alpha ms (+ (1-alpha) mc in tf mode)
-// mabs[pair] = max |M| as float bits (zeroed by the caller; the max of non-negative floats is the max of
-// their bit patterns and does not depend on the order of the atomics)
-__global__ void blend_matrix_kernel(const float* T, const float* mean, float* Mo, float* bias, unsigned* mabs,
-                                    int C, float alpha, int mode, int shared_style) {
-  __shared__ float red[4];
-  const int pair = blockIdx.y;
-  const size_t cc = (size_t)C * C;
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;      // first element; the grid strides over the matrix
-  float av = 0.f;
-  for (size_t e = i; e < cc; e += (size_t)gridDim.x * blockDim.x) {
-    float v = alpha * T[pair * cc + e];
-    if (e / C == e % C) v += 1.f - alpha;
-    Mo[pair * cc + e] = v;
-    av = fmaxf(av, fabsf(v));
-  }
-  for (int o = 32; o > 0; o >>= 1) av = fmaxf(av, __shfl_xor(av, o, 64));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = av;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    av = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (av < 1e30f) atomicMax(mabs + pair, __float_as_uint(av));       // one atomic per block
-  }
-  if (i < (size_t)C) {
-    const float* mp = mean + (size_t)pair * 2 * C;
-    const float* ms = mean + (size_t)(shared_style ? 0 : pair) * 2 * C + C;     // style mean
-    float b = alpha * ms[i];
-    if (mode == WCT_MODE_TF) b += (1.f - alpha) * mp[i];
-    bias[pair * C + i] = b;
-  }
-}
+// (the blend M = alpha T + (1 - alpha) I, max |M| and the bias vector: gemm_f32_kernel's blend epilogue and
+// spectral_open_all_kernel since round 5)
 
 
 // ---------------------------------------------------------------------------
@@ -2240,9 +2345,9 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   w.d = (float*)take((size_t)2 * P * C * sizeof(float));
   w.G = (float*)take(2 * P * cc);
   w.X = (float*)take(2 * P * cc);
-  w.S2 = (float*)take(5 * P * cc);
-  w.Tw = (float*)take(P * cc);
-  w.Tcs = (float*)take(P * cc);
+  w.S2 = (float*)take(7 * P * cc);          // second-order operands of a level, all matrices at once: N [2P], X2 [2P], R, Pm, X1 [P]
+  w.Tw = (float*)take(2 * P * cc);          // [2P][C][C] interleaved: whitening matrix of pair p at 2p, colouring matrix at 2p + 1
+  w.Tcs = w.Tw + (size_t)C * C;             // (style-swap path: one pair, Tw and Tcs side by side)
   w.T = (float*)take(P * cc);
   w.M = (float*)take(P * cc);
   w.bias = (float*)take((size_t)P * C * sizeof(float));
@@ -2267,12 +2372,13 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
   }
   sa.mean = nullptr; sa.partial = w.stat_partial; sa.absmax = w.absmax; sa.C = C; sa.nslab = w.nslab; sa.shared_style = shared_style;
   hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.mean, C, w.nslab, (float)Nc, (float)Ns, shared_style);
-  hipLaunchKernelGGL(cov_scale_kernel, dim3(2 * P), dim3(64), 0, s, w.absmax, w.scale, w.nslab, shared_style);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.mean, C, w.nslab, (float)Nc, (float)Ns, shared_style,
+                     (const float*)w.absmax, w.scale);
   if (with_var) {
     sa.mean = w.mean; sa.absmax = nullptr;
     hipLaunchKernelGGL(colsum_kernel, dim3(w.nslab, 2 * P), dim3(256), 0, s, sa);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.var, C, w.nslab, (float)Nc, (float)Ns, shared_style);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(C, 256), 2 * P), dim3(256), 0, s, w.stat_partial, w.var, C, w.nslab, (float)Nc, (float)Ns, shared_style,
+                       (const float*)nullptr, (float*)nullptr);
   }
   HIP_TRY(hipGetLastError());
   return WCT_OK;
@@ -2356,20 +2462,46 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   if (!(stages & WCT_STAGE_APPLY)) return WCT_OK;
 
   {
-    // Tw = Vc f_c(Ac) Vc^T, Tcs = Vs f_s(As) Vs^T with the first-order completion of f on the residual off-diagonals;
-    // the wct_np semantics shift the kept eigenvalues by eps inside the gains (ops.py:114,127), wct_tf does not
+    // Tw = Vc f_c(Ac) Vc^T, Tcs = Vs f_s(As) Vs^T with the first- and second-order completion of f on the residual
+    // off-diagonals; the wct_np semantics shift the kept eigenvalues by eps inside the gains (ops.py:114,127), wct_tf does not.
+    // One launch of each kind over all 2P matrices of the level (see spectral_open_all_kernel).
     const float shift = mode == WCT_MODE_NP ? (eps_in >= 0.f ? eps_in : 1e-5f) : 0.f;
-    if ((rc = launch_spectral_function(w.A, w.V, w.G, w.X, w.Tw, C, P, 2 * cc, cc, 0, shift, s, w.S2))) return rc;
-    if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.Tcs, C, shared_style ? 1 : P, 2 * cc, cc, 1, shift, s, w.S2))) return rc;
+    const int second = eig_correct_enabled() >= 2;
+    const dim3 tiles(cdiv(C, 64), cdiv(C, 64), 2 * P);
+    SpecAllArgs sa = {};
+    sa.A = w.A; sa.G = w.G; sa.C = C; sa.shift = shift; sa.correct = eig_correct_enabled(); sa.second = second; sa.shared_style = shared_style;
+    sa.N = w.S2; float* X2 = sa.N + 2 * P * cc; sa.R = X2 + 2 * P * cc; sa.Pm = sa.R + P * cc; float* X1 = sa.Pm + P * cc;
+    sa.X1 = X1; sa.X2 = X2;
+    sa.mabs = w.mabs; sa.mean = w.mean; sa.bias = w.bias; sa.alpha = alpha; sa.mode = mode;
+    hipLaunchKernelGGL(spectral_open_all_kernel, tiles, dim3(256), 0, s, sa);
+    if (second) {
+      GemmArgs a = {};   // X2[m] = (colouring: N[m], whitening: Pm[pair]) . N[m]
+      a.A = sa.Pm; a.sA = cc; a.A_odd = sa.N + cc; a.sA_odd = 2 * cc; a.lda = C; a.a_kmajor = 0;
+      a.B = sa.N; a.ldb = C; a.b_kmajor = 1; a.sB = cc; a.skip_shared = shared_style;
+      a.M = C; a.N = C; a.K = C; a.ksplit = C; a.out32 = X2; a.ldo = C; a.s_out = cc;
+      if ((rc = launch_gemm(a, 1, 2 * P, s))) return rc;
+      GemmArgs b = {};   // X1[pair] = R[pair] . N[2 pair]   (whitening side only)
+      b.A = sa.R; b.sA = cc; b.lda = C; b.a_kmajor = 0; b.B = sa.N; b.ldb = C; b.b_kmajor = 1; b.sB = 2 * cc;
+      b.M = C; b.N = C; b.K = C; b.ksplit = C; b.out32 = X1; b.ldo = C; b.s_out = cc;
+      if ((rc = launch_gemm(b, 1, P, s))) return rc;
+      hipLaunchKernelGGL(spectral_add2_all_kernel, tiles, dim3(256), 0, s, sa);
+    }
+    GemmArgs g = {};   // X[m] = V[m] G[m]
+    g.A = w.V; g.lda = C; g.a_kmajor = 0; g.B = w.G; g.ldb = C; g.b_kmajor = 1; g.sA = g.sB = cc; g.skip_shared = shared_style;
+    g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = w.X; g.ldo = C; g.s_out = cc;
+    if ((rc = launch_gemm(g, 1, 2 * P, s))) return rc;
+    GemmArgs h = {};   // Tw / Tcs [m] = X[m] V[m]^T
+    h.A = w.X; h.lda = C; h.a_kmajor = 0; h.B = w.V; h.ldb = C; h.b_kmajor = 0; h.sA = h.sB = cc; h.skip_shared = shared_style;
+    h.M = C; h.N = C; h.K = C; h.ksplit = C; h.out32 = w.Tw; h.ldo = C; h.s_out = cc;
+    if ((rc = launch_gemm(h, 1, 2 * P, s))) return rc;
   }
   {
-    GemmArgs g = {};   // T = Tcs . Tw
-    g.A = w.Tcs; g.lda = C; g.a_kmajor = 0; g.B = w.Tw; g.ldb = C; g.b_kmajor = 1; g.sA = shared_style ? 0 : cc; g.sB = cc;
-    g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = w.T; g.ldo = C; g.s_out = cc;
+    GemmArgs g = {};   // M = alpha (Tcs . Tw) + (1 - alpha) I, max |M| -> mabs: the blend in the product's epilogue
+    g.A = w.Tcs; g.lda = C; g.a_kmajor = 0; g.B = w.Tw; g.ldb = C; g.b_kmajor = 1; g.sA = shared_style ? 0 : 2 * cc; g.sB = 2 * cc;
+    g.M = C; g.N = C; g.K = C; g.ksplit = C; g.out32 = w.M; g.ldo = C; g.s_out = cc;
+    g.blend = 1; g.alpha = alpha; g.mabs = w.mabs;
     if ((rc = launch_gemm(g, 1, P, s))) return rc;
   }
-  HIP_TRY(hipMemsetAsync(w.mabs, 0, (size_t)P * sizeof(unsigned), s));
-  hipLaunchKernelGGL(blend_matrix_kernel, dim3((unsigned)(cc >= 16384 ? 16 : (cc + 255) / 256), P), dim3(256), 0, s, w.T, w.mean, w.M, w.bias, w.mabs, C, alpha, mode, shared_style);
   {  // out[n][j] = sum_k (x[n][k]-mc[k]) M[j][k] + bias[j]
     ApplyArgs a;
     a.x = content; a.N = Nc; a.C = C; a.mean = w.mean; a.M = w.M; a.bias = w.bias;
