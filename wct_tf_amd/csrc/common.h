@@ -68,6 +68,7 @@ struct ConvArgs {
   int upsample;        // input is the x2 nearest upsample of x (model.py:293)
   int relu;
   int pool;            // fuse the following 2x2/2 'same' max-pool: outputs are [(H+1)/2][(W+1)/2][Cout]
+  int xcd_map = 0;     // (tuning switch WCT_CONV_XCD) tile order that keeps the blocks of a pixel tile on one XCD (conv.hip)
   // feature statistics from the fp32 epilogue (null: off; need y32, relu, W % 16 == 0): usum [B][H*W/16][Cout] = the sum of
   // every run of 16 consecutive pixels (unit_row_sum's fixed tree -- what colsum_kernel computes from the stored features),
   // umax [B][UMAX_SLOTS] = bit patterns whose maximum is the largest value of the image (>= 0 after the ReLU), merged with

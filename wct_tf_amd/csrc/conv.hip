@@ -180,7 +180,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[N
 //    771 TFLOP/s over the layer mix vs 943 for this one.)
 //  * __launch_bounds__(256, 2): two blocks resident per CU cover each other's chunk boundaries.
 // ---------------------------------------------------------------------------
-template <int TH, int BN, int WM, int WN, bool FUSE1 = false>
+// WLDS (round 5, tuning builds: the block DESIGN 8.2 of rounds 3-4 asked for): BOTH operands of the implicit GEMM come out of
+// LDS.  The weights of a STAGE -- the three taps of one kernel row ky of the current K-chunk, BN x 3 x 32 fp16 = 48 KB for the
+// 256-channel block, already in MFMA A-fragment order in global memory -- are copied global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB = one fragment per wave instruction, no registers, lane-linear on both sides), one whole stage
+// ahead into the other of two buffers; a wave takes its fragments with ds_read_b128 at immediate offsets one tap ahead.  Every
+// weight byte enters the CU once per 256 pixels x 256 channels (the register path streams it once per wave: 2 x per 256 x 128).
+// Protocol: the barrier that opens the LAST tap of stage S (a) publishes stage S + 1 (issued a stage earlier; __syncthreads
+// drains the DMA queue because LDS-DMA sits on vmcnt) before the first fragment of its first tap is prefetched, and (b) retires
+// buffer S % 2 for every wave (its last fragment read was a tap earlier), so the DMA of stage S + 2 follows at once.
+template <int TH, int BN, int WM, int WN, bool FUSE1 = false, bool WLDS = false>
 __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles, int strip) {
   constexpr int PH = TH + 2;
   constexpr int MT = (TH / 2) / WM;
@@ -205,6 +214,10 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   // [pixel slot i][channel][thread] because the hardware writes lane l of a wave at base + 4 l; the 12-byte form of the
   // instruction did not land the pixels at base + 12 l -- parity test red -- and was worth 2.5 % of this kernel)
   constexpr int STG_OFF = B1_OFF + 256;
+  // WLDS: two weight-stage buffers behind the bias (1-KiB aligned): [cout tile BN/32][tap of the row 3][k-step 2][lane 64][16 B]
+  constexpr int WST_BYTES = (BN / 32) * 3 * 2 * 1024;
+  constexpr int WST_OFF = ((BIAS_OFF + BN * 4 + 1023) / 1024) * 1024;
+  static_assert(!WLDS || !FUSE1, "WLDS: generic loader only");
   static_assert(!FUSE1 || (BN == 64 && !(((TH / 2) / WM) * ((BN / 32) / WN) > 8)), "FUSE1: 64 output channels, single patch buffer");
   // tap at which the next K-chunk's patch loads are issued (their registers are live from there to the
   // chunk boundary only); the tall tile has no registers to spare and loads at the boundary
@@ -216,8 +229,17 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   [[maybe_unused]] bool ts_on = true;          // (-DCONV_TS) a strip block stamps its SECOND tile: entry = the end of the first
   TS(8);
   int bid = blockIdx.x;
-  const int ntile = bid % n_tiles;
+  int ntile = bid % n_tiles;
   bid /= n_tiles;
+  if (!FUSE1 && p.xcd_map) {
+    // (tuning switch) blocks reach the 8 XCDs round-robin by their linear index; with the channel tile running fastest the
+    // n_tiles blocks that read the SAME pixel patch sat on n_tiles different XCDs (every L2 fetched every patch).  Here the
+    // 8 consecutive indices of a group work on 8 different pixel tiles and the channel tile advances with the group:
+    // index = (pixel group * n_tiles + channel tile) * 8 + pixel in group -- the blocks of a pixel tile share an XCD.
+    const int lin = (int)blockIdx.x, g8 = lin >> 3;
+    ntile = g8 % n_tiles;
+    bid = (g8 / n_tiles) * 8 + (lin & 7);
+  }
   // FUSE1: a block walks a strip of `strip` horizontally adjacent tiles (the next tile's image patch is fetched under the
   // epilogue of the current one); blockIdx.x counts strips
   const int strips_x = FUSE1 ? (tiles_x + strip - 1) / strip : tiles_x;
@@ -288,6 +310,21 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7FFFFFFF, 0x00020000);
 
+  // WLDS: this wave's share of a stage: fragments f = wave, wave + 4, ... of the (BN / 32) * 6; fragment f = (ct * 3 + tap3) * 2 + ks
+  // = 1 KiB at p.w + ((n0 / 32 + ct) * 9 * c16 + (3 ky + tap3) * c16 + 2 chunk + ks) * 1024 bytes
+  auto dma_stage = [&](int stage) {           // stage = chunk * 3 + ky (uniform)
+    constexpr int NF = (BN / 32) * 6;
+    const int chunk = stage / 3, ky = stage - chunk * 3, bufw = stage & 1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);       // (M0 and the scalar offset must be SGPRs: no waterfall loops)
+#pragma unroll
+    for (int i = 0; i < NF / 4; ++i) {
+      const int f = wave_u + i * 4, ks = f & 1, t3 = (f >> 1) % 3, ct = (f >> 1) / 3;
+      // buffer form: SGPR resource + one loop-invariant lane offset + a scalar fragment offset -- no per-fragment VGPR address
+      const int soff = ((((n0 >> 5) + ct) * 9 + ky * 3 + t3) * c16 + chunk * 2 + ks) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, reinterpret_cast<__attribute__((address_space(3))) void*>(
+          (__attribute__((address_space(3))) unsigned char*)smem + WST_OFF + bufw * WST_BYTES + f * 1024), 16, lane * 16, soff, 0, 0);
+    }
+  };
   f32x16 acc[NT][MT];
   // the block's bias values -> LDS (read back by the epilogue; visible after the first patch barrier)
   if (tid < BN / 4 && strip_i == 0)
@@ -296,6 +333,20 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
   const int n_chunks = p.Cin / BK;           // even: Cin is a multiple of 64 on this path
   u32x4 patch_regs[PATCH_PER_THREAD];
   half8 wf[2][NT][2];                        // ping-pong weight fragments, loaded a full tap ahead
+  half8 wa[2][NT];                           // WLDS: ping-pong weight fragments by k-step, read out of LDS one k-step ahead
+  auto read_wfrag = [&](half8 (&dst)[NT], int stage, int t3, int ks) {     // the fragments of k-step ks of tap (stage, t3)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      dst[nt] = *reinterpret_cast<const half8*>(smem + WST_OFF + (stage & 1) * WST_BYTES +
+                                                ((((wn * NT + nt) * 3 + t3) * 2 + ks) * 64 + lane) * 16);
+  };
+  auto mma_group_w = [&](half8 (&w)[NT], half8 (&bq)[MT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[nt], bq[mt], acc[nt][mt], 0, 0, 0);
+  };
   half8 bf[2][MT];                           // ping-pong pixel fragments, read one k-step (8 MFMAs) ahead
 
   auto read_group = [&](half8 (&dst)[MT], int ky, int kx, int ks, int buf) {
@@ -461,19 +512,25 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
   } else {
     load_patch(0);
   }
+  if (WLDS) {
+    dma_stage(0);
+    if (n_chunks * 3 > 1) dma_stage(1);
+  } else {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      wf[0][nt][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wfrag[nt] + ks * 1024, 0, 0));
+      for (int ks = 0; ks < 2; ++ks)
+        wf[0][nt][ks] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wfrag[nt] + ks * 1024, 0, 0));
+  }
   if (FUSE1) {
     __syncthreads();
     make_patch(0);
   } else {
     store_patch(0);
   }
-  __syncthreads();
+  __syncthreads();                           // (WLDS: drains the DMA queue as well -- stages 0 and 1 are in LDS for every wave)
   TS(2);
+  if (WLDS) read_wfrag(wa[0], 0, 0, 0);
   read_group(bf[0], 0, 0, 0, 0);
 
 #pragma unroll 1
@@ -485,6 +542,40 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
       const int ntap = (tap + 1) % 9, nky = ntap / 3, nkx = ntap % 3;
       const bool more = chunk_i + 1 < n_chunks;
       const int buf = DB ? t / 9 : 0;            // compile-time: an immediate in the fragment reads
+      if constexpr (WLDS) {
+        // ---- both operands out of LDS.  wa[0] / bf[0] hold the fragments of this tap's first k-step (read during the previous
+        // tap), the second k-step's go out now; under ITS MFMAs the first k-step of the next tap is read -- across a stage
+        // boundary (kx = 2) behind the barrier that publishes the next stage's weights (and, at a chunk boundary, the next
+        // patch, parked in the other buffer just before: ONE barrier per stage, none per chunk).
+        const int stage = chunk_i * 3 + ky;
+        const bool last = stage + 1 >= n_chunks * 3;           // (uniform)
+        if (tap == PF_TAP && more) load_patch(chunk_i + 1);
+        read_group(bf[1], ky, kx, 1, buf);
+        read_wfrag(wa[1], stage, kx, 1);
+        if (DB && tap == 8 && more) store_patch(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group_w(wa[0], bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kx == 2) {
+          if (!last) {
+            __syncthreads();                                   // stage + 1 has landed for everybody; nobody reads this stage's buffer again
+            if (stage + 2 < n_chunks * 3) dma_stage(stage + 2);
+            read_wfrag(wa[0], stage + 1, 0, 0);
+            if (!DB && tap == 8) {                             // single patch buffer: it is free now (every wave's reads have returned)
+              store_patch(0);
+              __syncthreads();
+            }
+            read_group(bf[0], ky == 2 ? 0 : ky + 1, 0, 0, ky == 2 ? (DB ? buf ^ 1 : 0) : buf);
+          }
+        } else {
+          read_wfrag(wa[0], stage, kx + 1, 0);
+          read_group(bf[0], ky, kx + 1, 0, buf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group_w(wa[1], bf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       // 1) next tap's weight fragments (past the very end: re-read, unused); the next patch leaves PF_TAP early
       {
         const int nchunk = tap == 8 ? (more ? chunk_i + 1 : chunk_i) : chunk_i;
@@ -547,19 +638,23 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
 #endif
 }
 
-template <int TH, int BN, int WM, int WN, bool FUSE1 = false>
+template <int TH, int BN, int WM, int WN, bool FUSE1 = false, bool WLDS = false>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
   const int n_tiles = a.Cout / BN;
   constexpr int PH = TH + 2;
   constexpr int NBUF = ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 2 : 1;
-  const size_t lds = (size_t)NBUF * (PH * PITCH * 64 + 4096) + BN * sizeof(float)      // NBUF x (patch, dump slots), bias
-                     + (FUSE1 ? (size_t)(TH + 4) * 20 * 3 * 4 + 64 + 8192 + 256 + 9 * 1024 : 0);  // image patch, zero words, conv1_1 weights and bias, landing area
+  size_t lds = (size_t)NBUF * (PH * PITCH * 64 + 4096) + BN * sizeof(float)      // NBUF x (patch, dump slots), bias
+               + (FUSE1 ? (size_t)(TH + 4) * 20 * 3 * 4 + 64 + 8192 + 256 + 9 * 1024 : 0);  // image patch, zero words, conv1_1 weights and bias, landing area
+  if (WLDS) lds = ((lds + 1023) / 1024) * 1024 + 2 * (size_t)(BN / 32) * 3 * 2 * 1024;      // two weight-stage buffers
   // FUSE1: strips of 4 / 2 tiles per block while that leaves the chip >= 4 blocks per resident slot (512 slots)
   const long tiles = (long)tiles_x * tiles_y * a.B;
   static const int strip_force = tune_int("WCT_FUSE1_STRIP", 0);   // tuning switch
   const int strip = !FUSE1 ? 1 : strip_force ? strip_force : tiles >= 8192 ? 4 : tiles >= 4096 ? 2 : 1;
   dim3 grid((FUSE1 ? cdiv(tiles_x, strip) : tiles_x) * tiles_y * n_tiles, a.B);
+  ConvArgs ax = a;
+  static const int xcd = tune_int("WCT_CONV_XCD", 0);     // tuning switch: XCD-aware tile order (needs a multiple of 8 pixel tiles per image)
+  ax.xcd_map = !FUSE1 && xcd && (tiles_x * tiles_y) % 8 == 0;
   if (lds > 64 * 1024) {
     // more dynamic LDS than the 64 KiB a runtime may enforce by default (gfx950 has 160 KiB per CU): say so, once per device
     // and instantiation; a refusal surfaces here and not at a later synchronisation
@@ -567,12 +662,12 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !raised[dev]) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1, WLDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       raised[dev] = true;
     }
   }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1>), grid, dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles, strip);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1, WLDS>), grid, dim3(256), lds, s, ax, tiles_x, tiles_y, n_tiles, strip);
 #ifdef CONV_TS
   if (a.B >= 8) {
     static int nlaunch = 0;
@@ -616,6 +711,8 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
     ARG_CHECK(a.Cin == 64 && a.Cout == 64 && !a.upsample && a.w1frag && a.bias1);
     return launch_conv_cfg<32, 64, 4, 1, true>(a, s);
   }
+  const long px16 = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.B;
+  const long px32 = (long)cdiv(a.W, TW) * cdiv(a.H, 32) * a.B;
   static const int force = tune_int("WCT_CONV_CFG", 0);   // tuning switch
   if (force == 1 && a.Cout % 128 == 0) return launch_conv_cfg<16, 128, 2, 2>(a, s);
   if (force == 2) return launch_conv_cfg<32, 64, 4, 1>(a, s);
@@ -628,12 +725,15 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   //  Kept as a switch: the starting point of DESIGN 8.2)
 #ifdef WCT_TUNING      // (2 VGPR spills: not instantiated in the product build -- VERDICT r4)
   if (force == 5 && a.Cout % 256 == 0) return launch_conv_cfg<16, 256, 2, 2>(a, s);
+  // (round 5: the same block with BOTH operands through LDS -- weights by LDS-DMA a stage ahead; see the kernel's WLDS note)
+  if (force == 6 && a.Cout % 256 == 0) return launch_conv_cfg<16, 256, 2, 2, false, true>(a, s);
+  if (force == 7 && a.Cout % 256 == 0 && px16 * (a.Cout / 256) >= 256) return launch_conv_cfg<16, 256, 2, 2, false, true>(a, s);
+  // ... and on the shipped 256-pixel x 128-channel block: 76 KB of LDS, still two blocks per CU
+  if (force == 8 && a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) return launch_conv_cfg<16, 128, 2, 2, false, true>(a, s);
 #endif
   // (round 2: <32,64,2,2> and <16,128,1,4> -- the waves of a block split the output channels instead of the pixels,
   //  halving / removing the redundant weight streams -- measured 593 vs 601 TFLOP/s on 64->64 @512^2 and 5-8 % slower on
   //  the wide layers, profiles/r02_conv_cfg_sweep.txt: the weight streams are not what bounds these layers; removed)
-  const long px16 = (long)cdiv(a.W, TW) * cdiv(a.H, 16) * a.B;
-  const long px32 = (long)cdiv(a.W, TW) * cdiv(a.H, 32) * a.B;
   if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) return launch_conv_cfg<16, 128, 2, 2>(a, s);
   if (px32 * (a.Cout / 64) >= 512) return launch_conv_cfg<32, 64, 4, 1>(a, s);      // 512 px x 64 ch
   if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_conv_cfg<16, 128, 2, 2>(a, s);
