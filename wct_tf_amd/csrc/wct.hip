@@ -1059,17 +1059,48 @@ struct VStripArgs {
   int mat_major; // grid (nmat, strips) instead of (strips, nmat): see vstrip_launch
 };
 
+// Round 5: the rotation log reaches the block by LDS-DMA into a RING of VS_RING tiles (buffer_load_dwordx4 ... lds, 1 KiB per wave
+// instruction, no registers), VS_RING - 1 tiles ahead of the one in use.  Until round 4 a tile was requested four pairs ahead into
+// 64 VGPRs and parked in a two-tile LDS buffer: with ~2 us per access (the log streams from HBM: 64 MB per segment at 64 matrices)
+// and ~0.2 us of MFMA work per tile a block waited nine tenths of its life, and while it waits it holds a whole CU (414 registers
+// per lane: no pair-problem or update wave fits beside it) -- the V pass cost the solve a quarter of its time at batch 32 although
+// it runs on its own stream.  Protocol per tile q: s_waitcnt vmcnt((VS_RING - 2) x NDMA) retires this wave's share of tile q (the
+// counter is in order), the barrier makes it everybody's and retires slot (q - 1) % VS_RING, whose refill (tile q + VS_RING - 1)
+// is issued at once.  Past the end of the segment the refills re-fetch the last tile into slots nobody reads: the outstanding
+// count stays constant and so does the wait.
+constexpr int VS_RING = 8;
+template <int M2, int W>
+constexpr size_t vstrip_lds_bytes() { return (size_t)VS_RING * M2 * M2 * sizeof(float); }
+
 template <int M2, int NBLK, int W>
 __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
   constexpr int B = M2 / 2, TB = B / 16, NCH = M2 / 32, NPAIR = NBLK / 2, FR = M2 * M2, C = NBLK * B;
-  constexpr int NLD = FR / 4 / (W * 64) > 0 ? FR / 4 / (W * 64) : 1;        // float4 per thread and tile
-  __shared__ __attribute__((aligned(16))) float qs[2][FR];
+  constexpr int TILE_BYTES = FR * 4;                       // fp16 hi / lo fragments of one rotation matrix
+  constexpr int NDMA = TILE_BYTES / 1024 / W;              // 1-KiB DMA pieces per wave and tile
+  static_assert(NDMA >= 1 && NDMA * W * 1024 == TILE_BYTES, "a tile is a whole number of 1-KiB pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char vs_ring[];
   const int m = p.mat_major ? blockIdx.x : blockIdx.y;
   if (p.st[m].seg_stop <= p.seg || JDBG(p)) return;   // no rotations of this segment belong to the matrix (done before it began)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
   const int row0 = ((p.mat_major ? blockIdx.y : blockIdx.x) * W + wave) * 16;
   float* Vm = p.V + (size_t)m * C * C + (size_t)(row0 + li) * C + 4 * lq;
+  const size_t slot_stride = (size_t)p.nmat * NPAIR * FR;
+  const float* qbase = reinterpret_cast<const float*>(p.Qlog) + (size_t)m * NPAIR * FR;   // a tile of fp16 hi/lo fragments = FR * 4 bytes too
+  // tile q of the segment: step = step_begin + q / NPAIR, pair = q % NPAIR
+  const int ntile = (p.step_end - p.step_begin) * NPAIR;
+  const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, 0x7FFFFFFF, 0x00020000);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma = [&](int q) {                                  // (uniform) tile min(q, ntile - 1) -> ring slot q % VS_RING
+    const int qq = q < ntile ? q : ntile - 1;
+    const unsigned soff = (unsigned)(((size_t)(qq / NPAIR) * slot_stride + (size_t)(qq % NPAIR) * FR) * sizeof(float));
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int piece = wave_u + i * W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rsrc, reinterpret_cast<__attribute__((address_space(3))) void*>(
+          (__attribute__((address_space(3))) unsigned char*)vs_ring + (q % VS_RING) * TILE_BYTES + piece * 1024), 16, lane * 16, soff + piece * 1024, 0, 0);
+    }
+  };
   f32x4 v[NBLK * TB];
   auto block_at = [&](int pos, int step) { return step < 0 ? pos : rr_idx(pos, step, NBLK); };
 #pragma unroll
@@ -1078,50 +1109,21 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
 #pragma unroll
     for (int tb = 0; tb < TB; ++tb) v[pos * TB + tb] = *reinterpret_cast<const f32x4*>(Vm + blk * B + tb * 16);
   }
-  const size_t slot_stride = (size_t)p.nmat * NPAIR * FR;
-  const float* qbase = reinterpret_cast<const float*>(p.Qlog) + (size_t)m * NPAIR * FR;   // a tile of fp16 hi/lo fragments = FR * 4 bytes too
-  // tile q of the segment: step = step_begin + q / NPAIR, pair = q % NPAIR
-  const int ntile = (p.step_end - p.step_begin) * NPAIR;
-  // The rotation log streams from HBM (128 MB per segment at 64 matrices): ~2 us per access.  A tile is requested
-  // PD pairs before it is used (PD register sets, one per pair of a step where the step has that many), parked in LDS
-  // one pair ahead; with a single tile in flight the kernel ran at one memory latency per pair (260 us per launch).
-  constexpr int PD = NPAIR < 4 ? NPAIR : 4;
-  f32x4 pre[PD][NLD];
-  auto fetch = [&](int q, auto SET) {
-    constexpr int set = decltype(SET)::value;
-    const float* src = qbase + (size_t)(q / NPAIR) * slot_stride + (size_t)(q % NPAIR) * FR;
+  // (the strip's loads are OLDER than the DMAs on the in-order counter: the first tile's wait then covers the strip and tile 0 only)
+  asm volatile("" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int f = tid + i * W * 64;
-      if (FR / 4 >= W * 64 || f < FR / 4) pre[set][i] = *reinterpret_cast<const f32x4*>(src + (size_t)f * 4);
-    }
-  };
-  auto park = [&](auto SET, int buf) {
-    constexpr int set = decltype(SET)::value;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int f = tid + i * W * 64;
-      if (FR / 4 >= W * 64 || f < FR / 4) *reinterpret_cast<f32x4*>(&qs[buf][f * 4]) = pre[set][i];
-    }
-  };
-  {
-    // tiles 0 .. PD-1 of the segment into the register sets (a segment has at least NPAIR >= PD tiles)
-    auto prime = [&](auto I) { fetch(decltype(I)::value, I); };
-    prime(std::integral_constant<int, 0>{});
-    if constexpr (PD > 1) prime(std::integral_constant<int, 1>{});
-    if constexpr (PD > 2) { prime(std::integral_constant<int, 2>{}); prime(std::integral_constant<int, 3>{}); }
-    if constexpr (PD > 4) { prime(std::integral_constant<int, 4>{}); prime(std::integral_constant<int, 5>{}); prime(std::integral_constant<int, 6>{}); prime(std::integral_constant<int, 7>{}); }
-  }
-  park(std::integral_constant<int, 0>{}, 0);
-  __syncthreads();
+  for (int q0 = 0; q0 < VS_RING - 1; ++q0) dma(q0);       // tiles 0 .. VS_RING - 2
   int q = 0;
   // one pair (the g-th of its step: g is a compile-time constant once the loops below are unrolled, and so are the
   // positions pa / pb and the register sets g % PD, (g + 1) % PD): tiles x = positions pa, pb;
   // out[mt] = sum over chunks of the three split-operand MFMAs.  The strip must stay in registers.
 #define VSTRIP_PAIR(pa, pb, g)                                                                                       \
   {                                                                                                                  \
-    if (q + PD < ntile) fetch(q + PD, std::integral_constant<int, (g) % PD>{});   /* the set tile q came from is free */ \
-    const half_t* qb = reinterpret_cast<const half_t*>(qs[q & 1]);                                                   \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VS_RING - 2) * NDMA) : "memory");   /* this wave's pieces of tile q have landed */ \
+    __builtin_amdgcn_s_barrier();                          /* ... everybody's; and nobody reads tile q - 1 any more */ \
+    asm volatile("" ::: "memory");                                                                                   \
+    dma(q + VS_RING - 1);                                                                                            \
+    const half_t* qb = reinterpret_cast<const half_t*>(vs_ring + (q % VS_RING) * TILE_BYTES);                        \
     f32x4 out[2 * TB];                                                                                               \
     _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};                      \
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                                \
@@ -1140,8 +1142,6 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
       }                                                                                                              \
     }                                                                                                                \
     _Pragma("unroll") for (int t = 0; t < TB; ++t) { v[(pa) * TB + t] = out[t]; v[(pb) * TB + t] = out[TB + t]; }    \
-    if (q + 1 < ntile) park(std::integral_constant<int, ((g) + 1) % PD>{}, (q + 1) & 1);                             \
-    __syncthreads();                                                                                                 \
     ++q;                                                                                                             \
   }
   // (the loops over g are spelled out with compile-time g: `#pragma unroll` alone leaves g a variable inside the macro)
@@ -1171,6 +1171,7 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
     }
   }
 #undef VSTRIP_PAIR
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the refills past the end are still landing in this block's LDS
   const int last = p.step_end - 1;
 #pragma unroll
   for (int pos = 0; pos < NBLK; ++pos) {
@@ -1599,7 +1600,16 @@ static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_
   static const int xcd = tune_int("WCT_JACOBI_XCD", 1);
   a.mat_major = xcd && G.nmat % 8 == 0;
 #define VSTRIP_CASE(m2, nb, w) \
-  if (M2 == m2 && nblk == nb) hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), a.mat_major ? dim3(G.nmat, C / 16 / w) : dim3(C / 16 / w, G.nmat), dim3(w * 64), 0, s, a);
+  if (M2 == m2 && nblk == nb) {                                                                                      \
+    static bool raised[16] = {};                                                                                     \
+    int dev = 0;                                                                                                     \
+    const size_t vs_lds = (vstrip_lds_bytes<m2, w>());                                                               \
+    if (vs_lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && !raised[dev]) {            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_vstrip_kernel<m2, nb, w>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds); \
+      raised[dev] = true;                                                                                            \
+    }                                                                                                                \
+    hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), a.mat_major ? dim3(G.nmat, C / 16 / w) : dim3(C / 16 / w, G.nmat), dim3(w * 64), vs_lds, s, a); \
+  }
   VSTRIP_CASE(64, 16, 4) VSTRIP_CASE(64, 8, 8) VSTRIP_CASE(32, 8, 4) VSTRIP_CASE(32, 4, 4) VSTRIP_CASE(32, 2, 2)
 #undef VSTRIP_CASE
 }
