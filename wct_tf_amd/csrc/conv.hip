@@ -940,24 +940,37 @@ __global__ __launch_bounds__(256) void conv_last_kernel(ConvLastArgs p, int tile
   half8 wf[4];                                             // A fragments: rows tap*3+co, k = 16 ks + 8 (lane>>5) ..
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wf[ks] = *reinterpret_cast<const half8*>(p.wfrag + (ks * 64 + lane) * 8);
-  for (int tile = wave; tile < 11; tile += 4) {            // 324 patch pixels = 11 tiles of 32 (the last one partial)
+  // 324 patch pixels = 11 tiles of 32 (the last one partial), tiles wave, wave + 4, wave + 8 per wave.  Round 5: ALL of a wave's
+  // activation loads (up to 3 tiles x 4 x 16 B per lane) are issued before the first MFMA -- the kernel is a read stream (3.7 TB/s
+  // with one tile's loads in flight per wave: a memory latency per tile) with three blocks per CU to hide it behind.
+  half8 bf[3][4];
+  int qs[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int tile = wave + 4 * i;                         // (wave-uniform; tile 11 does not exist: wave 3 has two tiles)
     const int q = tile * 32 + (lane & 31);
+    qs[i] = q;
     const int qq = q < 324 ? q : 323;
     const int py = qq / 18, px = qq - py * 18;
     const int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(x0 - 1 + px, p.W);
     const half_t* src = xb + ((size_t)iy * p.W + ix) * 64 + (lane >> 5) * 8;
-    half8 bf[4];
+    if (tile < 11) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bf[ks] = *reinterpret_cast<const half8*>(src + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) bf[i][ks] = *reinterpret_cast<const half8*>(src + ks * 16);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (wave + 4 * i >= 11) break;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bf[ks], acc, 0, 0, 0);
-    if (q < 324) {
+    for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bf[i][ks], acc, 0, 0, 0);
+    if (qs[i] < 324) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)                         // register r = row (r&3) + 8 (r>>2) + 4 (lane>>5)
-        part[q * PP + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = acc[r];
+        part[qs[i] * PP + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = acc[r];
     }
   }
   __syncthreads();
