@@ -118,7 +118,7 @@ def pmc_traffic(batch, size):
     """HBM bytes per conv3x3 launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
     runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read from inside this
     process, so the figure is the profile of this exact workload, not a measurement of this run; null otherwise."""
-    for tag in ('r04_final', 'r03_final', 'r02_final', 'r01_final'):
+    for tag in ('r05_final', 'r04_final', 'r03_final', 'r02_final', 'r01_final'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_conv3x3.json' % tag)
         if batch == PMC_BATCH and size == 512 and os.path.exists(path):
             return json.load(open(path))['hbm_bytes_per_launch_corrected'], 'profiles/%s_pmc_hbm.csv' % tag
@@ -509,8 +509,8 @@ def main():
                 'note': 'batched two-sided block Jacobi on the %d-level covariances (C = 512, 512, 256, 128, 64; content and style); '
                         'look-ahead launches {pair problems of step s, tile update of step s-1}; from 256 channels on the 64 x 64 pair '
                         'problems are resident in REGISTERS (256 threads, 1 x W strips of cells, rim exchange through LDS, scaled '
-                        'rotations: one fma per output; four blocks of a launch per CU; round 4); V '
-                        'resident in registers per launch segment from 24 matrices per solve on; second-order completion of the '
+                        'rotations: one fma per output, cells as separate S / Q scalars: 60 v_fma per lane and set; four blocks of a launch per CU); V '
+                        'resident in registers per launch segment from 24 matrices per solve on (rotation log by LDS-DMA into a ring of 8 tiles); second-order completion of the '
                         'spectral functions; second-largest time class' % len(LEVELS)}
             line['breakdown_ms_per_step'] = {k: v['ms'] / args.steps for k, v in prof.items()}
         if world == 1 and not args.no_latency and not args.shared_style:

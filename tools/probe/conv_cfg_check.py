@@ -8,6 +8,9 @@ from wct_tf_amd.context import Context
 min_cout = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 SHAPES = [(256, 256, 128, 128, 0), (256, 256, 64, 64, 1), (512, 512, 64, 64, 0), (512, 512, 32, 32, 1), (512, 256, 64, 64, 0), (128, 256, 128, 128, 0),
           (256, 512, 37, 53, 0), (512, 512, 2, 2, 0), (512, 512, 16, 48, 0), (64, 256, 50, 18, 1), (512, 512, 31, 17, 1)]
+if os.environ.get('CONV_CHECK_TALL'):      # tall images (a batch emulated by height): enough tiles for the strip variants of the narrow layers
+    SHAPES = [(64, 64, 4096, 512, 0), (64, 64, 2048, 256, 1), (64, 128, 4096, 256, 0), (128, 128, 4096, 256, 0), (128, 128, 2048, 128, 1),
+              (128, 64, 4096, 256, 0), (64, 64, 4099, 515, 0), (64, 64, 2051, 253, 1)]
 ctx = Context(0)
 rng = np.random.default_rng(5)
 h = hashlib.sha256()
@@ -21,4 +24,4 @@ for cin, cout, hh, ww, up in SHAPES:
     d = hashlib.sha256(np.ascontiguousarray(y).tobytes()).hexdigest()
     h.update(d.encode())
     print('%3d->%3d %3dx%3d up=%d: %s  (mean %.5f)' % (cin, cout, hh, ww, up, d[:12], float(y.mean())))
-print('CFG=%s XCD=%s digest %s' % (os.environ.get('WCT_CONV_CFG', '-'), os.environ.get('WCT_CONV_XCD', '-'), h.hexdigest()[:16]))
+print('CFG=%s XCD=%s STRIPS=%s digest %s' % (os.environ.get('WCT_CONV_CFG', '-'), os.environ.get('WCT_CONV_XCD', '-'), os.environ.get('WCT_CONV_STRIPS', '-'), h.hexdigest()[:16]))

@@ -189,8 +189,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[N
 // Protocol: the barrier that opens the LAST tap of stage S (a) publishes stage S + 1 (issued a stage earlier; __syncthreads
 // drains the DMA queue because LDS-DMA sits on vmcnt) before the first fragment of its first tap is prefetched, and (b) retires
 // buffer S % 2 for every wave (its last fragment read was a tap earlier), so the DMA of stage S + 2 follows at once.
-template <int TH, int BN, int WM, int WN, bool FUSE1 = false, bool WLDS = false>
+// STRIPS (round 5): the generic loader walks a strip of horizontally adjacent tiles as well, and the FIRST patch of the next tile
+// is copied global -> LDS by LDS-DMA (no registers) under the current tile's epilogue.  A 64-channel layer has two K-chunks per
+// tile: its first patch (7 k cycles of exposed latency, profiles/r02_conv_phase_timing.txt) and its epilogue were 45 % of a tile.
+template <int TH, int BN, int WM, int WN, bool FUSE1 = false, bool WLDS = false, bool STRIPS = false>
 __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2) void conv3x3_mfma_kernel(ConvArgs p, int tiles_x, int tiles_y, int n_tiles, int strip) {
+  constexpr bool LOOP = FUSE1 || STRIPS;           // the block walks `strip` tiles
+  static_assert(!(FUSE1 && STRIPS) && !(WLDS && STRIPS), "one loader variant at a time");
   constexpr int PH = TH + 2;
   constexpr int MT = (TH / 2) / WM;
   constexpr int NT = (BN / 32) / WN;
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(256, ((TH / 2) / WM) * ((BN / 32) / WN) > 8 ? 1 : 2
   }
   // FUSE1: a block walks a strip of `strip` horizontally adjacent tiles (the next tile's image patch is fetched under the
   // epilogue of the current one); blockIdx.x counts strips
-  const int strips_x = FUSE1 ? (tiles_x + strip - 1) / strip : tiles_x;
-  const int tx = FUSE1 ? (bid % strips_x) * strip : bid % strips_x;
+  const int strips_x = LOOP ? (tiles_x + strip - 1) / strip : tiles_x;
+  const int tx = LOOP ? (bid % strips_x) * strip : bid % strips_x;
   const int ty = bid / strips_x;
   const int b = blockIdx.y;
   int y0 = ty * TH;
@@ -256,7 +261,7 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
   // (thread index and tile row are made opaque per iteration: hoisted out of the strip loop, everything that depends on the lane
   //  and y0 only -- fragment addresses, reflected rows, patch and store offsets -- stayed live across the tile's epilogue and
   //  27 registers were spilled; recomputing them costs a few dozen instructions per tile)
-  if (FUSE1) asm volatile("" : "+v"(tid_), "+s"(y0));
+  if (LOOP) asm volatile("" : "+v"(tid_), "+s"(y0));
   ts_on = !FUSE1 || strip < 2 || strip_i == 1;
   if (FUSE1 && strip >= 2) TS(8);
   const int tid = tid_;
@@ -310,6 +315,29 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7FFFFFFF, 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7FFFFFFF, 0x00020000);
 
+  // STRIPS: chunk 0 of the patch of the tile at xt, global -> LDS.  One wave instruction fills 64 consecutive 16-byte slots of
+  // the [PH][PITCH] x 4 slot image (lane-linear destination); the XOR swizzle of patch_dst is applied on the SOURCE side
+  // (slot s of pixel px takes channel piece s ^ ((px >> 2) & 3)), the two padding pixels of a row re-read pixel 17, and the
+  // lanes past the image (half an instruction) land in the dump area behind it.
+  auto dma_patch0 = [&](int xt) {
+    constexpr int NINS = (PH * PITCH * 4 + 63) / 64;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll 1                         // (rolled: unrolled, the eleven lane offsets live at once next to the accumulators spilled 62 registers)
+    for (int i0 = 0; i0 < (NINS + 3) / 4; ++i0) {
+      const int i = wave_u + i0 * 4;
+      if (i < NINS) {                                          // (uniform)
+        const int d = i * 64 + lane, ps = d >> 2, slot = d & 3;
+        int py = ps / PITCH;
+        const int px = ps - py * PITCH;
+        py = py < PH ? py : PH - 1;
+        int iy = reflect_idx(y0 - 1 + py, p.H), ix = reflect_idx(xt - 1 + (px < 18 ? px : 17), p.W);
+        if (p.upsample) { iy >>= 1; ix >>= 1; }
+        const int piece = slot ^ ((px >> 2) & 3);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, reinterpret_cast<__attribute__((address_space(3))) void*>(
+            (__attribute__((address_space(3))) unsigned char*)smem + i * 1024), 16, ((iy * Win + ix) * p.Cin + piece * 8) * 2, 0, 0, 0);
+      }
+    }
+  };
   // WLDS: this wave's share of a stage: fragments f = wave, wave + 4, ... of the (BN / 32) * 6; fragment f = (ct * 3 + tap3) * 2 + ks
   // = 1 KiB at p.w + ((n0 / 32 + ct) * 9 * c16 + (3 ky + tap3) * c16 + 2 chunk + ks) * 1024 bytes
   auto dma_stage = [&](int stage) {           // stage = chunk * 3 + ky (uniform)
@@ -509,6 +537,10 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
     // (the image patch in LDS was last read by the previous tile's second make_patch, which ends in a barrier)
     park_img();
     TS(9);
+  } else if (STRIPS) {
+    // the first patch of EVERY tile of a strip comes by LDS-DMA: the first tile's here, the others' under the previous epilogue
+    // (one code path: a register-path first patch beside it left part of patch_regs in scratch memory)
+    if (strip_i == 0) dma_patch0(x0);
   } else {
     load_patch(0);
   }
@@ -525,6 +557,8 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
   if (FUSE1) {
     __syncthreads();
     make_patch(0);
+  } else if (STRIPS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the patch (and everything older) have landed
   } else {
     store_patch(0);
   }
@@ -621,8 +655,12 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
     }
   }
   TS(5);
-  const bool more_tiles = FUSE1 && strip_i + 1 < strip && tx + strip_i + 1 < tiles_x;      // uniform
-  if (more_tiles) fetch_img(x0 + TW);        // arrives under the epilogue (whose stores sit on the same in-order counter)
+  const bool more_tiles = LOOP && strip_i + 1 < strip && tx + strip_i + 1 < tiles_x;      // uniform
+  if (FUSE1 && more_tiles) fetch_img(x0 + TW);        // arrives under the epilogue (whose stores sit on the same in-order counter)
+  if (STRIPS && more_tiles) {
+    __syncthreads();                         // every wave has taken its last fragments out of the patch
+    dma_patch0(x0 + TW);
+  }
   TS(0);
   conv_epilogue<MT, NT>(p, acc, b, y0, x0, n0, wm, wn, lane, smem + BIAS_OFF);
   TS(6);
@@ -638,7 +676,7 @@ next_tile:   // (FUSE1: the strip loop -- the whole body; otherwise passed once)
 #endif
 }
 
-template <int TH, int BN, int WM, int WN, bool FUSE1 = false, bool WLDS = false>
+template <int TH, int BN, int WM, int WN, bool FUSE1 = false, bool WLDS = false, bool STRIPS = false>
 static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH);
   const int n_tiles = a.Cout / BN;
@@ -650,11 +688,11 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
   // FUSE1: strips of 4 / 2 tiles per block while that leaves the chip >= 4 blocks per resident slot (512 slots)
   const long tiles = (long)tiles_x * tiles_y * a.B;
   static const int strip_force = tune_int("WCT_FUSE1_STRIP", 0);   // tuning switch
-  const int strip = !FUSE1 ? 1 : strip_force ? strip_force : tiles >= 8192 ? 4 : tiles >= 4096 ? 2 : 1;
-  dim3 grid((FUSE1 ? cdiv(tiles_x, strip) : tiles_x) * tiles_y * n_tiles, a.B);
+  const int strip = !(FUSE1 || STRIPS) ? 1 : strip_force ? strip_force : tiles >= 8192 ? 4 : tiles >= 4096 ? 2 : 1;
+  dim3 grid(((FUSE1 || STRIPS) ? cdiv(tiles_x, strip) : tiles_x) * tiles_y * n_tiles, a.B);
   ConvArgs ax = a;
   static const int xcd = tune_int("WCT_CONV_XCD", 0);     // tuning switch: XCD-aware tile order (needs a multiple of 8 pixel tiles per image)
-  ax.xcd_map = !FUSE1 && xcd && (tiles_x * tiles_y) % 8 == 0;
+  ax.xcd_map = !FUSE1 && !STRIPS && xcd && (tiles_x * tiles_y) % 8 == 0;
   if (lds > 64 * 1024) {
     // more dynamic LDS than the 64 KiB a runtime may enforce by default (gfx950 has 160 KiB per CU): say so, once per device
     // and instantiation; a refusal surfaces here and not at a later synchronisation
@@ -662,12 +700,12 @@ static int launch_conv_cfg(const ConvArgs& a, hipStream_t s) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 16 && !raised[dev]) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1, WLDS>),
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1, WLDS, STRIPS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       raised[dev] = true;
     }
   }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1, WLDS>), grid, dim3(256), lds, s, ax, tiles_x, tiles_y, n_tiles, strip);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<TH, BN, WM, WN, FUSE1, WLDS, STRIPS>), grid, dim3(256), lds, s, ax, tiles_x, tiles_y, n_tiles, strip);
 #ifdef CONV_TS
   if (a.B >= 8) {
     static int nlaunch = 0;
@@ -734,6 +772,18 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   // (round 2: <32,64,2,2> and <16,128,1,4> -- the waves of a block split the output channels instead of the pixels,
   //  halving / removing the redundant weight streams -- measured 593 vs 601 TFLOP/s on 64->64 @512^2 and 5-8 % slower on
   //  the wide layers, profiles/r02_conv_cfg_sweep.txt: the weight streams are not what bounds these layers; removed)
+#ifdef WCT_TUNING
+  // (round 5, tuning builds: WCT_CONV_STRIPS=1 -- strips with the next tile's first patch by LDS-DMA under the epilogue, on the layers
+  //  with few K-chunks per tile and many tiles.  Bit-identical, 10 % SLOWER on 64 -> 64 @512 (0.194 -> 0.215 ms at batch 8,
+  //  profiles/r05_conv_strips.txt): the strip serialises a tile's store drain with the next tile's start, which two independent
+  //  blocks per CU overlap for free)
+  static const int strips_on = tune_int("WCT_CONV_STRIPS", 0);
+  if (strips_on && a.Cin <= 128) {
+    if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512 && px16 >= 4096) return launch_conv_cfg<16, 128, 2, 2, false, false, true>(a, s);
+    if (!(a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) && px32 * (a.Cout / 64) >= 512 && px32 >= 4096)
+      return launch_conv_cfg<32, 64, 4, 1, false, false, true>(a, s);
+  }
+#endif
   if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 512) return launch_conv_cfg<16, 128, 2, 2>(a, s);
   if (px32 * (a.Cout / 64) >= 512) return launch_conv_cfg<32, 64, 4, 1>(a, s);      // 512 px x 64 ch
   if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_conv_cfg<16, 128, 2, 2>(a, s);
