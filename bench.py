@@ -416,7 +416,7 @@ def main():
     # N = 1: what configs[3] would take -- 64 pairs per step over 8 GPUs is 8 pairs per GPU: the batch-8 step of THIS GPU
     # against its own time for all 64 pairs (two 32-pair calls); the gather is not in it
     proj = None
-    if world == 1 and not strong and not args.shared_style and args.batch == 32:
+    if world == 1 and not strong and not args.shared_style and args.batch == 32 and not args.no_latency:      # (an extra leg, like the latency: profile passes skip it)
         dt8 = measure(8, args.steps, 2, False)[0]
         dt64, _, _, _, i64 = measure(64, max(1, args.steps // 2), 1, False)
         ms8, ms64 = 1e3 * dt8 / args.steps, 1e3 * dt64 / max(1, args.steps // 2)

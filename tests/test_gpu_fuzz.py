@@ -74,10 +74,12 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
         cand = [list(range(r[0], r[1] + 1)) for r in ranges]
     else:
         cand = [sorted({r[0], min(r[0] + 1, r[1]), max(r[1] - 1, r[0]), r[1]}) for r in ranges]
+    wide = max(r[1] - r[0] for r in ranges) >= 8
     errs = {}
     for kc in cand[0]:
         for ks in cand[1]:
-            errs[(kc, ks)] = rel_err(got, np.asarray(fn(*shaped, alpha, keep=(kc, ks))).reshape(nc, c))
+            # (wide bands are judged against the float64 outcomes below: the float32 ones are not evaluated -- two SVDs apiece)
+            errs[(kc, ks)] = float('nan') if wide else rel_err(got, np.asarray(fn(*shaped, alpha, keep=(kc, ks))).reshape(nc, c))
     # A WIDE band is a whole cluster of rounding-noise eigenvalues sitting on the cut-off (N < C pixels at a feature
     # scale whose noise is ~1e-5 or above): every noise direction the reference happens to keep is amplified by up to
     # (1e-5)^-1/2 = 316, and its own output is then rounding noise at the 1e-3..1e-2 level -- measured here as the
@@ -90,7 +92,6 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     # different order and its eigenvectors carry different round-off) is a second, independent draw: on bands of eight or
     # more noise eigenvalues the two draws have been measured up to ~10x `own` apart (C = 96..256, N = 4: 1.0e-3 .. 2.4e-3
     # with own 1e-4 .. 2e-4) -- the tolerance there is 2e-3 or 8x own; narrow bands keep 1e-3 or 4x own
-    wide = max(r[1] - r[0] for r in ranges) >= 8
     STATS['wct_indeterminate'] += own > 2.5e-4
     print('near cut-off: C=%d N=%d/%d scale 1e%.1f kept-count band %s: best rel %.2e (reference fp32 vs fp64 on this input: %.2e)'
           % (c, nc, ns, log_scale, ranges, min(errs.values()), own))
