@@ -1077,6 +1077,7 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
   constexpr int B = M2 / 2, TB = B / 16, NCH = M2 / 32, NPAIR = NBLK / 2, FR = M2 * M2, C = NBLK * B;
   constexpr int TILE_BYTES = FR * 4;                       // fp16 hi / lo fragments of one rotation matrix
   constexpr int NDMA = TILE_BYTES / 1024 / W;              // 1-KiB DMA pieces per wave and tile
+  constexpr bool FRAGS_AHEAD = W <= 4;                     // one wave per SIMD: registers to hold a tile's 16 fragments at once
   static_assert(NDMA >= 1 && NDMA * W * 1024 == TILE_BYTES, "a tile is a whole number of 1-KiB pieces per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char vs_ring[];
   const int m = p.mat_major ? blockIdx.x : blockIdx.y;
@@ -1126,21 +1127,31 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
     const half_t* qb = reinterpret_cast<const half_t*>(vs_ring + (q % VS_RING) * TILE_BYTES);                        \
     f32x4 out[2 * TB];                                                                                               \
     _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};                      \
+    /* ALL fragments of the tile are requested before the first MFMA (round 5: hipcc read them one at a time, each   \
+       ds_read_b128 followed by s_waitcnt lgkmcnt(0) and its MFMAs -- sixteen exposed LDS round trips per pair, and   \
+       the three MFMAs of an accumulator back to back: 100 us of a block's 115).  Per accumulator the order of the    \
+       six products is unchanged (chunk 0: lo.hi, hi.lo, hi.hi; chunk 1 likewise): the same bits. */                \
+    half8 fa[NCH][2 * TB][2];                                                                                        \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                                  \
+      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                          \
+        _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                       \
+          fa[c][mt][part] = *reinterpret_cast<const half8*>(qb + (((mt * NCH + c) * 2 + part) * 64 + lane) * 8);     \
+    if (FRAGS_AHEAD) __builtin_amdgcn_sched_barrier(0);   /* (two waves per SIMD: 256 registers -- let the compiler read just in time) */ \
+    half8 bh[NCH], bl[NCH];                                                                                          \
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                                \
       /* tiles 2c, 2c+1 of the pair's 2 TB tiles: positions pa (tiles 0..TB-1) and pb (TB..2TB-1) */                 \
       const f32x4 x0 = 2 * c < TB ? v[(pa) * TB + 2 * c] : v[(pb) * TB + 2 * c - TB];                                \
       const f32x4 x1 = 2 * c + 1 < TB ? v[(pa) * TB + 2 * c + 1] : v[(pb) * TB + 2 * c + 1 - TB];                    \
       const float xx[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};                                  \
-      half8 bh, bl;                                                                                                  \
-      split_f16x8(xx, bh, bl);                                                                                       \
-      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) {                                                        \
-        const half8 ah = *reinterpret_cast<const half8*>(qb + (((mt * NCH + c) * 2 + 0) * 64 + lane) * 8);           \
-        const half8 al = *reinterpret_cast<const half8*>(qb + (((mt * NCH + c) * 2 + 1) * 64 + lane) * 8);           \
-        out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, out[mt], 0, 0, 0);                                  \
-        out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, out[mt], 0, 0, 0);                                  \
-        out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, out[mt], 0, 0, 0);                                  \
-      }                                                                                                              \
+      split_f16x8(xx, bh[c], bl[c]);                                                                                 \
     }                                                                                                                \
+    if (FRAGS_AHEAD) __builtin_amdgcn_sched_barrier(0);                                                              \
+    _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                                \
+      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[c][mt][1], bh[c], out[mt], 0, 0, 0); \
+      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[c][mt][0], bl[c], out[mt], 0, 0, 0); \
+      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[c][mt][0], bh[c], out[mt], 0, 0, 0); \
+    }                                                                                                                \
+    if (FRAGS_AHEAD) __builtin_amdgcn_sched_barrier(0);                                                              \
     _Pragma("unroll") for (int t = 0; t < TB; ++t) { v[(pa) * TB + t] = out[t]; v[(pb) * TB + t] = out[TB + t]; }    \
     ++q;                                                                                                             \
   }
