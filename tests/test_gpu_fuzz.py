@@ -102,18 +102,15 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     # rounding noise, or this path's own error?  Both fp32 evaluations are measured against the EXACT answer: the oracle in
     # float64 at every kept count of the band.  `ref_noise` = how far the reference's own float32 arithmetic lands from the
     # nearest exact outcome; `gpu_exact` = the same for this path.
-    # RESULT (MI355X, round 5, profiles/r05_parity_holes.txt): the excess is THIS PATH'S, not reference noise.  On N = 4 pixels
-    # (rank-3 covariances, C = 96 / 512, eigenvalues 4e3 / 2e3 / 1e3 and then rounding noise 3e-5 .. 8e-4 on the kept side
-    # of the cut-off) the reference's float32 lands 9.5e-5 / 9.9e-5 from the exact outcome, this path 1.06e-3 / 1.27e-3.
-    # Emulating the path's split-fp16 covariance in NumPy and finishing with LAPACK gives 1.05e-4 / 7.9e-5 -- the covariance
-    # is not it.  What is: the eigenvector matrix V is accumulated with 22-bit products (V <- V Q on split fp16) over ~200 block
-    # rotations, so a kept NOISE direction carries a component ~3e-6 along the three large directions where LAPACK's carries
-    # ~1e-7; its gain (1e-5)^-1/2 .. is 100-180 and the content's component along a large direction ~60: 140 x 3e-6 x 60 / |out|
-    # ~ 1e-3.  It needs kept noise eigenvalues 8 decades below the norm -- N << C at feature scales that lift rounding noise
-    # over the absolute cut-off; a covariance of the metric's levels (N >= 1024 pixels) has none.  A second run of the sweep
-    # (other examples: the shrink phase is off now) found the same at N = 75 / 95 < C = 256, scale 1e0.9: this path 2.36e-3
-    # from the exact outcome, the reference's float32 4.63e-4 -- five times, as in the N = 4 cases (ten times).  Budget in THIS
-    # regime: 2e-3 against the exact outcome, or 6x the reference's own loss where that is larger; everywhere else 1e-3 stands.
+    # RESULT (MI355X, round 5, profiles/r05_parity_holes.txt): the excess WAS this path's, not reference noise -- on N << C inputs
+    # (rank-deficient covariances whose rounding-noise eigenvalues the absolute cut-off keeps, 8 decades below the norm) the
+    # reference's float32 landed 9.5e-5 .. 4.6e-4 from the exact outcome and this path 1.06e-3 .. 2.36e-3.  Cause: the solver
+    # tracks the rotated matrix D + E and the eigenvectors V separately (fp32 tile updates; 22-bit products), so V^T A0 V = D + E
+    # held only to ~1e-6 ||A||, and the spectral functions' completion took that inconsistency for signal; a kept noise direction
+    # has a gain of up to 316.  FIX (csrc/wct.hip refresh_needed): for a matrix with a kept eigenvalue 4 decades below its
+    # largest the rotated matrix is RECOMPUTED, E' = V^T A0 V, before the spectral functions -- f(A0) = V f(V^T A0 V) V^T is then
+    # exact for orthogonal V.  After it the same cases read 3.5e-5 (was 2.36e-3; reference 4.6e-4), 6.1e-7 (5.2e-4; 4.4e-5),
+    # 4.1e-6 (7.2e-4; 1.3e-4): the stated budget holds again -- 1e-3, or 4x what the reference's arithmetic loses on the input.
     STATS['wct_wide'] += 1
     sh64 = (np.float64(shaped[0]), np.float64(shaped[1]))
     kw64 = {'dtype': np.float64} if mode == 'tf' else {}
@@ -123,7 +120,7 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     STATS['wct_wide_worst'] = max(STATS['wct_wide_worst'], gpu_exact)
     print('   wide band: vs the exact (float64) outcomes of the band: this path %.2e, the reference in float32 %.2e'
           % (gpu_exact, ref_noise))
-    assert gpu_exact < max(2e-3, 6 * ref_noise), (c, nc, ns, alpha, mode, log_scale, gpu_exact, ref_noise)
+    assert gpu_exact < max(1e-3, 4 * ref_noise), (c, nc, ns, alpha, mode, log_scale, gpu_exact, ref_noise)
 
 
 @settings(max_examples=30, **COMMON)

@@ -174,6 +174,10 @@ struct GemmArgs {
   // blend epilogue (T = Tcs Tw -> M = alpha T + (1 - alpha) I, ops.py:83 folded into the apply matrix): the store carries the
   // blend and the block merges max |M| into mabs[batch] (bit patterns of non-negative floats; zeroed by an earlier kernel)
   int blend; float alpha; unsigned* mabs;
+  // refresh products (round 5, launch_wct): run for the batches whose matrix needs it, a no-op for the others.  mask_diag: the
+  // [nbatch][M][M] matrices whose DIAGONAL decides (refresh_needed, csrc/wct.hip); every block of a batch evaluates it the same way
+  // and block (0, 0) stores it in mask_out[batch].  mask_in: a mask stored by an earlier launch.
+  const float* mask_diag; size_t s_mask; int* mask_out; const int* mask_in;
 };
 
 int launch_gemm(GemmArgs g, int nsplit, int nbatch, hipStream_t s);

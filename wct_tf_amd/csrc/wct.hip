@@ -209,6 +209,35 @@ struct GemmStage {
   }
 };
 
+// Round 5: does the rotated matrix D + E the solver hands over need a REFRESH, E' = V^T A0 V recomputed from the eigenvectors
+// and the untouched covariance?  The solver tracks the rotated matrix (fp32 tile updates, ~80 of them per element) and V (22-bit
+// products, ~200 block rotations) separately, so V^T A0 V = D + E holds only to ~1e-6 ||A||.  The spectral functions take f(A0) =
+// V f(D + E) V^T with E to first / second order: an inconsistency of 1e-6 ||A|| in E is harmless while the kept eigenvalues are
+// within a few decades of the norm, and is the whole error (1e-3 .. 2e-3 of the transform, tests/test_gpu_fuzz.py wide bands) once
+// kept eigenvalues sit 4+ decades below it -- rank-deficient covariances whose rounding noise the absolute 1e-5 cut-off keeps, gain
+// up to 316.  With E' the identity f(A0) = V f(V^T A0 V) V^T is exact for orthogonal V whatever the sweeps left behind (NumPy model of
+// the failing case: 3.3e-3 with the tracked E, 1.3e-6 with E', V in 22 bits either way).  Cost: two C^3 products per matrix that
+// needs it, none for the others (the blocks of a batch whose predicate is false exit at once).
+// Predicate (from the tracked diagonal = eigenvalue estimates): an eigenvalue that is kept, or within half a decade below the
+// cut-off, and below 1e-4 of the largest.
+constexpr float REFRESH_RATIO = 1e-4f;
+__device__ __forceinline__ bool refresh_needed(const float* Am, int C, int tid) {     // all 256 threads of a block; contains barriers
+  float dmax = 0.f, dmin = 3.0e38f;
+  for (int i = tid; i < C; i += 256) {
+    const float d = Am[(size_t)i * C + i];
+    dmax = fmaxf(dmax, fabsf(d));
+    // kept, or within half a decade below the cut-off (spectral_add2_kernel's `near` band: its side of the cut-off is not settled)
+    if (d > 3.3e-6f) dmin = fminf(dmin, d);
+  }
+  for (int o = 32; o > 0; o >>= 1) { dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); dmin = fminf(dmin, __shfl_xor(dmin, o, 64)); }
+  __shared__ float red[2][4];
+  if ((tid & 63) == 0) { red[0][tid >> 6] = dmax; red[1][tid >> 6] = dmin; }
+  __syncthreads();
+  dmax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  dmin = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+  return dmin < 3.0e38f && dmin < REFRESH_RATIO * dmax;
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave (2x2 waves)
@@ -220,6 +249,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int batch = blockIdx.z / p.nsplit, split = blockIdx.z % p.nsplit;
   if (p.skip_shared && skip_style_mat(batch, 1)) return;
+  if (p.mask_in && !p.mask_in[batch]) return;
+  if (p.mask_diag) {                             // (uniform per block)
+    const bool need = refresh_needed(p.mask_diag + batch * p.s_mask, p.M, tid);
+    if (p.mask_out && blockIdx.x == 0 && blockIdx.y == 0 && split == 0 && tid == 0) p.mask_out[batch] = need ? 1 : 0;
+    if (!need) return;
+  }
   const int kbeg = split * p.ksplit;
   const int kend = min(p.K, kbeg + p.ksplit);
   if (p.A_odd) p.A = (batch & 1) ? p.A_odd + (batch >> 1) * p.sA_odd : p.A + (batch >> 1) * p.sA;
@@ -499,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void cov_f16x2_kernel(CovArgs p) {
 //  them in LDS; element by element the lower triangle walked columns of every partial.  Same sums in the same order.)
 // grid (C / 64, C / 64, 2P)
 __global__ __launch_bounds__(256) void cov_finish_kernel(const float* partial, const float* scale, float* cov, int C, int nsplit, int BT,
-                                                         float inv0, float inv1, float eps, int shared_style) {
+                                                         float inv0, float inv1, float eps, int shared_style, float* cov0 = nullptr) {
   __shared__ float tt[64][65];
   const int mat = blockIdx.z;             // 2*pair + side
   if (skip_style_mat(mat, shared_style)) return;
@@ -538,6 +573,7 @@ __global__ __launch_bounds__(256) void cov_finish_kernel(const float* partial, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (r == c + j) v[j] += eps;
     *reinterpret_cast<f32x4*>(cov + (size_t)mat * cc + (size_t)r * C + c) = v;
+    if (cov0) *reinterpret_cast<f32x4*>(cov0 + (size_t)mat * cc + (size_t)r * C + c) = v;     // (the copy the solver does not rotate: refresh_needed)
   }
 }
 
@@ -2324,8 +2360,8 @@ __global__ __launch_bounds__(256, 2) void apply_f16x2_kernel(ApplyArgs p) {
 static inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct WctCarve {
-  float *mean, *var, *stat_partial, *absmax, *scale, *cov_partial, *A, *V, *d, *G, *X, *S2, *Tw, *Tcs, *T, *M, *bias;
-  unsigned* mabs;
+  float *mean, *var, *stat_partial, *absmax, *scale, *cov_partial, *A, *A0, *V, *d, *G, *X, *S2, *Tw, *Tcs, *T, *M, *bias;
+  unsigned* mabs; int* refresh;
   void* jacobi_ws; size_t jacobi_bytes;
   int nslab, nsplit, ksplit;
   size_t total;
@@ -2362,6 +2398,8 @@ static WctCarve carve(void* base, int C, int Nc, int Ns, int P) {
   w.scale = (float*)take((size_t)2 * P * sizeof(float));
   w.cov_partial = (float*)take((size_t)2 * P * w.nsplit * cc);
   w.A = (float*)take(2 * P * cc);
+  w.A0 = (float*)take(2 * P * cc);          // the covariances as computed (the solver rotates w.A in place)
+  w.refresh = (int*)take((size_t)2 * P * sizeof(int));
   w.V = (float*)take(2 * P * cc);
   w.d = (float*)take((size_t)2 * P * C * sizeof(float));
   w.G = (float*)take(2 * P * cc);
@@ -2436,7 +2474,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   const float eps_user = eps_in >= 0.f ? eps_in : (mode == WCT_MODE_TF ? 1e-8f : 1e-5f);
   const float eps = mode == WCT_MODE_TF ? eps_user : 0.f;
   hipLaunchKernelGGL(cov_finish_kernel, dim3(cdiv(C, 64), cdiv(C, 64), 2 * P), dim3(256), 0, s,
-                     w.cov_partial, w.scale, w.A, C, w.nsplit, BT, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps, shared_style);
+                     w.cov_partial, w.scale, w.A, C, w.nsplit, BT, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps, shared_style, w.A0);
   }
   if (stages & WCT_STAGE_EIG) {
     if (nside > 0 && P >= 2) {
@@ -2489,6 +2527,20 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
     const float shift = mode == WCT_MODE_NP ? (eps_in >= 0.f ? eps_in : 1e-5f) : 0.f;
     const int second = eig_correct_enabled() >= 2;
     const dim3 tiles(cdiv(C, 64), cdiv(C, 64), 2 * P);
+    {
+      // refresh (see refresh_needed): X = A0 V, then A <- V^T X, for the matrices whose kept spectrum reaches 4 decades below
+      // their norm; the others' blocks exit at once
+      GemmArgs r1 = {};
+      r1.A = w.A0; r1.lda = C; r1.a_kmajor = 0; r1.B = w.V; r1.ldb = C; r1.b_kmajor = 1; r1.sA = r1.sB = cc; r1.skip_shared = shared_style;
+      r1.M = C; r1.N = C; r1.K = C; r1.ksplit = C; r1.out32 = w.X; r1.ldo = C; r1.s_out = cc;
+      r1.mask_diag = w.A; r1.s_mask = cc; r1.mask_out = w.refresh;
+      if ((rc = launch_gemm(r1, 1, 2 * P, s))) return rc;
+      GemmArgs r2 = {};
+      r2.A = w.V; r2.lda = C; r2.a_kmajor = 1; r2.B = w.X; r2.ldb = C; r2.b_kmajor = 1; r2.sA = r2.sB = cc; r2.skip_shared = shared_style;
+      r2.M = C; r2.N = C; r2.K = C; r2.ksplit = C; r2.out32 = w.A; r2.ldo = C; r2.s_out = cc;
+      r2.mask_in = w.refresh;
+      if ((rc = launch_gemm(r2, 1, 2 * P, s))) return rc;
+    }
     SpecAllArgs sa = {};
     sa.A = w.A; sa.G = w.G; sa.C = C; sa.shift = shift; sa.correct = eig_correct_enabled(); sa.second = second; sa.shared_style = shared_style;
     sa.N = w.S2; float* X2 = sa.N + 2 * P * cc; sa.R = X2 + 2 * P * cc; sa.Pm = sa.R + P * cc; float* X1 = sa.Pm + P * cc;
