@@ -88,10 +88,8 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     o32 = np.asarray(fn(*shaped, alpha)).reshape(nc, c)
     o64 = np.asarray(fn(np.float64(shaped[0]), np.float64(shaped[1]), alpha, **({'dtype': np.float64} if mode == 'tf' else {}))).reshape(nc, c)
     own = rel_err(o32, o64)
-    # o32 vs o64 is ONE draw of that rounding noise; another fp32 evaluation (this path's covariance sums its products in a
-    # different order and its eigenvectors carry different round-off) is a second, independent draw: on bands of eight or
-    # more noise eigenvalues the two draws have been measured up to ~10x `own` apart (C = 96..256, N = 4: 1.0e-3 .. 2.4e-3
-    # with own 1e-4 .. 2e-4) -- the tolerance there is 2e-3 or 8x own; narrow bands keep 1e-3 or 4x own
+    # o32 vs o64 is ONE draw of that rounding noise: narrow bands are judged against the float32 outcomes with 1e-3 or 4x `own`;
+    # wide ones (eight or more noise eigenvalues on the cut-off) against the EXACT outcomes, below
     STATS['wct_indeterminate'] += own > 2.5e-4
     print('near cut-off: C=%d N=%d/%d scale 1e%.1f kept-count band %s: best rel %.2e (reference fp32 vs fp64 on this input: %.2e)'
           % (c, nc, ns, log_scale, ranges, min(errs.values()), own))

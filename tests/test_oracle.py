@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 import oracle
-from conftest import GOLDEN, rel_err, max_rel, check_against_size_digest
+from conftest import ROOT, GOLDEN, rel_err, max_rel, check_against_size_digest
 from wct_tf_amd.weights import (synthetic_weights, synthetic_features, synthetic_image,
                                 decoder_plan)
 
@@ -293,3 +293,20 @@ def test_wct_style_swap_properties():
     s_flat = fs[0].reshape(-1, 16)
     d = np.abs(out1[:, None, :] - s_flat[None, :, :]).max(-1).min(-1)
     assert d.max() < 2e-3 * np.abs(s_flat).max()
+
+
+def test_refresh_model_tracked_rotated_matrix_is_the_error_recomputed_one_is_not():
+    """The experiment behind the eigen-stage's refresh (csrc/wct.hip refresh_needed), kept as a regression test of
+    the ARGUMENT: a NumPy model of the solver (cyclic Jacobi in float32, eigenvectors rounded to 22 bits like the split-fp16
+    products, first-order completion of the spectral functions) on a rank-deficient covariance (C = 96, N = 4) whose rounding-noise
+    eigenvalues the reference's absolute cut-off keeps.  With the TRACKED rotated matrix the transform is 3e-3 from the nearest
+    exact outcome -- 30x the reference's own float32 error; with the rotated matrix RECOMPUTED from the eigenvectors and the
+    untouched covariance it is at 1e-6, whatever the eigenvectors' precision and whatever the sweeps left behind."""
+    import runpy
+    mod = runpy.run_path(os.path.join(ROOT, 'tools', 'probe', 'diag_nllc.py'))
+    r = mod['run']()
+    assert 5e-5 < r['reference'] < 2e-4
+    for name in ('V fp32', 'V 22-bit', 'V 22-bit tol 1e-6'):
+        assert r[(name, 'refreshed')] < 1e-5 < r['reference'], (name, r)
+    assert r[('V 22-bit', 'tracked')] > 1e-3 and r[('V 22-bit tol 1e-6', 'tracked')] > 1e-3, r     # more sweeps do not help
+    assert r[('V 22-bit', 'no completion')] > 1e-3, r                                             # nor does dropping the completion

@@ -2,7 +2,9 @@
 completion of the spectral functions on (a) the TRACKED rotated matrix, (b) the rotated matrix recomputed from V and the untouched covariance.  Round 5: the
 experiment behind refresh_needed (csrc/wct.hip).  Result: profiles/r05_parity_holes.txt."""
 import numpy as np, sys
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import os
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import oracle
 from conftest import rel_err
 def features(rng, n, c, scale, mix=True):
@@ -50,7 +52,7 @@ def jacobi(A0, vbits=None, sweeps_max=16, tol=1e-2):
 def spectral(A,kind,shift,first_order=True):
     d=np.diag(A).astype(np.float64); C=len(d); E=A.astype(np.float64)-np.diag(d)
     kept=d>1e-5
-    f=np.where(kept,(d+shift)**(-0.5 if kind==0 else 0.5),0.0)
+    f=np.where(kept,np.where(kept,d+shift,1.0)**(-0.5 if kind==0 else 0.5),0.0)
     G=np.diag(f)
     if first_order:
         sa=np.sqrt(np.where(kept,d+shift,1.0))
@@ -69,19 +71,24 @@ def transform(fc,fs,alpha,Ac,Vc,As,Vs,shift=1e-5):
     x=(fc-fc.mean(0)).astype(np.float64)
     out=alpha*((Tcs@Tw@x.T).T+fs.mean(0))+(1-alpha)*x
     return out
-c,alpha=96,1.0
-fc,fs=case(96,2,2,2,2,1.0,0)
-shaped=(fc.reshape(1,2,2,c),fs.reshape(1,2,2,c))
-exact={}
-for kc in range(1,40):
-    for ks in (3,):
-        exact[(kc,ks)]=np.asarray(oracle.wct_np(np.float64(shaped[0]),np.float64(shaped[1]),alpha,keep=(kc,ks))).reshape(4,c)
-def best(o): return min(rel_err(o,e) for e in exact.values())
-o32=np.asarray(oracle.wct_np(*shaped,alpha)).reshape(4,c); print('reference fp32 vs exact',best(o32))
-covc=np.cov(fc.T.astype(np.float64)).astype(f32); covs=np.cov(fs.T.astype(np.float64)).astype(f32)
-for vb,name,tl in ((None,"V fp32",1e-4),(22,"V 22-bit",1e-4),(22,"V 22-bit tol 1e-6",1e-6)):
-    Ac,Vc,sc=jacobi(covc,vb,16,tl); As,Vs,ss=jacobi(covs,vb,16,tl)
-    o=transform(fc,fs,alpha,Ac,Vc,As,Vs); print(name,'sweeps',sc,ss,'tracked-E completion:',best(o), ' V orth err',np.abs(Vc.T.astype(np.float64)@Vc-np.eye(c)).max())
-    Ac2=(Vc.astype(np.float64).T@covc.astype(np.float64)@Vc.astype(np.float64)); As2=(Vs.astype(np.float64).T@covs.astype(np.float64)@Vs.astype(np.float64))
-    o=transform(fc,fs,alpha,Ac2,Vc,As2,Vs); print(name,'refreshed E = V^T A0 V:',best(o))
-    o=transform(fc,fs,alpha,np.diag(np.diag(Ac)),Vc,np.diag(np.diag(As)),Vs); print(name,'no completion:',best(o))
+def run(verbose=False):
+    """-> {'reference': r, (name, what): distance}: distances to the nearest exact (float64) outcome of the kept-count band"""
+    c,alpha=96,1.0
+    fc,fs=case(96,2,2,2,2,1.0,0)
+    shaped=(fc.reshape(1,2,2,c),fs.reshape(1,2,2,c))
+    exact=[np.asarray(oracle.wct_np(np.float64(shaped[0]),np.float64(shaped[1]),alpha,keep=(kc,3))).reshape(4,c) for kc in range(1,40)]
+    def best(o): return min(rel_err(o,e) for e in exact)
+    out={'reference': best(np.asarray(oracle.wct_np(*shaped,alpha)).reshape(4,c))}
+    covc=np.cov(fc.T.astype(np.float64)).astype(f32); covs=np.cov(fs.T.astype(np.float64)).astype(f32)
+    for vb,name,tl in ((None,"V fp32",1e-4),(22,"V 22-bit",1e-4),(22,"V 22-bit tol 1e-6",1e-6)):
+        Ac,Vc,sc=jacobi(covc,vb,16,tl); As,Vs,ss=jacobi(covs,vb,16,tl)
+        out[(name,'tracked')]=best(transform(fc,fs,alpha,Ac,Vc,As,Vs))
+        Vc64,Vs64=Vc.astype(np.float64),Vs.astype(np.float64)
+        out[(name,'refreshed')]=best(transform(fc,fs,alpha,Vc64.T@covc.astype(np.float64)@Vc64,Vc,Vs64.T@covs.astype(np.float64)@Vs64,Vs))
+        out[(name,'no completion')]=best(transform(fc,fs,alpha,np.diag(np.diag(Ac)),Vc,np.diag(np.diag(As)),Vs))
+        out[(name,'sweeps')]=(sc,ss); out[(name,'V orth err')]=np.abs(Vc64.T@Vc64-np.eye(c)).max()
+    if verbose:
+        for k,v in out.items(): print(k,v)
+    return out
+if __name__=='__main__':
+    run(True)
