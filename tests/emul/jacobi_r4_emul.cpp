@@ -4,8 +4,9 @@
 //      full 64 x 64 matrices one after the other (the routing of tools/jacobi_patch_proto.py, now on the kernel source);
 //   2. tile update U(s): P_new == J^T P J and V_new == V J with J assembled from the kernel's own rotation matrices;
 //   3. look-ahead D(s+1): the pair problems assembled from {images of D(s), one MFMA block} == those loaded from P_new;
-//   4. the fp16 hi + lo fragments reproduce Q to 2^-20;   5. the intra step (256 threads, four cells per thread): Q
-//      orthogonal, S_out == Q^T S_in Q, every intra pair visited (the two diagonal blocks come out diagonal-dominant).
+//   4. the fp16 hi + lo fragments reproduce Q to 2^-20;   5. the intra step (round 5: one wave per 32-wide block, odd-even
+//      transposition ordering in registers, the off-diagonal block by two MFMA products): S image and Q == the sequential sets
+//      in double, statistics, every index pair of a block met exactly once, Q orthogonal, S_out == Q^T S_in Q.
 // Prints one line per check; exit status 0 iff all hold.
 #include "hip_emul.h"
 namespace emul { thread_local Idx tidx; thread_local Idx bidx; thread_local Block* blk; }
@@ -84,6 +85,41 @@ static void reference_cross(const double* S0, double* S, double* Q) {
     mm(S, J.data(), T.data(), false); mm(J.data(), T.data(), S, true);
     mm(Q, J.data(), T.data(), false); memcpy(Q, T.data(), sizeof(double) * FR);
   }
+}
+
+// the intra step's ordering (r4::intra_wave): odd-even transposition with exchange on the positions of each 32-wide block -- even
+// sets rotate the position pairs (0,1)(2,3).., odd sets (1,2)..(29,30); position p takes s x_p + c x_q, position q takes c x_p - s x_q
+static double ref_offmax_intra = 0;
+static int intra_pairs_seen = 0;
+static void reference_intra(const double* S0, double* S, double* Q) {
+  std::vector<double> G(FR), T(FR);
+  std::vector<int> seen(FR, 0);
+  int idx[2][B];
+  for (int h = 0; h < 2; ++h) for (int i = 0; i < B; ++i) idx[h][i] = i;
+  for (int i = 0; i < FR; ++i) { S[i] = S0[i]; Q[i] = (i / M2 == i % M2); }
+  auto mm = [&](const double* X, const double* Y, double* Z, bool xt) {
+    for (int i = 0; i < M2; ++i) for (int j = 0; j < M2; ++j) {
+      double a = 0; for (int k = 0; k < M2; ++k) a += (xt ? X[k * M2 + i] : X[i * M2 + k]) * Y[k * M2 + j];
+      Z[i * M2 + j] = a; }
+  };
+  for (int s = 0; s < B; ++s) {
+    for (int i = 0; i < FR; ++i) G[i] = (i / M2 == i % M2);
+    for (int h = 0; h < 2; ++h)
+      for (int x = s & 1; x + 1 < B; x += 2) {
+        const int p = h * B + x, q = p + 1;
+        double c, sn;
+        ref_offmax_intra = std::max(ref_offmax_intra, std::min(1.0, fabs(S[p * M2 + q]) / sqrt(fabs(S[p * M2 + p] * S[q * M2 + q]))));
+        rot(S[p * M2 + p], S[q * M2 + q], S[p * M2 + q], c, sn);
+        G[p * M2 + p] = sn; G[q * M2 + p] = c; G[p * M2 + q] = c; G[q * M2 + q] = -sn;
+        const int ip = idx[h][x], iq = idx[h][x + 1];
+        seen[std::min(ip, iq) * B + std::max(ip, iq)] += 1;
+        idx[h][x] = iq; idx[h][x + 1] = ip;
+      }
+    mm(S, G.data(), T.data(), false); mm(G.data(), T.data(), S, true);
+    mm(Q, G.data(), T.data(), false); memcpy(Q, T.data(), sizeof(double) * FR);
+  }
+  intra_pairs_seen = 0;
+  for (int i = 0; i < B; ++i) for (int j = i + 1; j < B; ++j) intra_pairs_seen += seen[i * B + j] == 2;    // once in each of the two blocks
 }
 
 struct Solver {
@@ -223,7 +259,7 @@ int main() {
     T.P[0] = A0;
     JacobiFusedArgs ai = T.args(0, 0, 0, 0, -1, -2, true, false, true, true);
     T.run_d(ai);
-    double eO = 0, eS = 0, dom = 0;
+    double eO = 0, eS = 0, dom = 0, eSr = 0, eQr = 0;
     for (int g = 0; g < T.npair; ++g) {
       int bi, bj;
       pair_blocks(g, -1, T.nblk, bi, bj);
@@ -240,6 +276,17 @@ int main() {
         off0 += S0[(h * B + r) * M2 + h * B + c] * S0[(h * B + r) * M2 + h * B + c];
         off1 += R[(h * B + r) * M2 + h * B + c] * R[(h * B + r) * M2 + h * B + c]; }
       dom = std::max(dom, sqrt(off1 / off0));
+      std::vector<double> Sr(FR), Qr(FR);
+      reference_intra(S0.data(), Sr.data(), Qr.data());
+      for (int i = 0; i < FR; ++i) { eSr = std::max(eSr, fabs(ai.Sw[(size_t)g * FR + i] - Sr[i]) / nrm); eQr = std::max(eQr, fabs(Q[i] - Qr[i])); }
+    }
+    check("intra step: every index pair of a block meets exactly once in the 32 sets (pairs missing of 496)", 496 - intra_pairs_seen, 0);
+    check("intra step: S image vs the sequential odd-even sets, relative to max |S|", eSr, 2e-5);
+    check("intra step: rotation matrix Q vs the sequential odd-even sets", eQr, 2e-5);
+    {
+      const double offmax = __builtin_bit_cast(float, T.st.offmax), offsig = __builtin_bit_cast(float, T.st.offsig);
+      check("intra step: largest relative pivot seen by the sets (offmax) vs the sequential sets", fabs(offmax - ref_offmax_intra) / ref_offmax_intra, 1e-4);
+      check("intra step: the same over the significant pairs (floor 0: all of them)", fabs(offsig - ref_offmax_intra) / ref_offmax_intra, 1e-4);
     }
     check("intra step: Q^T Q - I", eO, 1e-5);
     check("intra step: S image vs Q^T S_in Q, relative", eS, 2e-5);

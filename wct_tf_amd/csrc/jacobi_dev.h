@@ -400,7 +400,7 @@ constexpr size_t lds_bytes(int has_d, int has_u, int first, int step_d) {
   constexpr size_t F = sizeof(float);
   size_t need = 0;
   if (has_d) {
-    if (step_d < 0) need = 2 * M2 * (M2 + 1) * 2 * F + 4 * M2 * F;                     // intra sets: two {S, Q} images, D, O, dummy
+    if (step_d < 0) need = (2 * SIMG_F + (M2 / 2) * (M2 / 2 + 4)) * F;                 // intra step: S and Q images, W of the off-diagonal product
     else {
       need = SIMG_F * F + Xchg<LAY>::BYTES;                                            // S image (pitch SP), exchange area
       if (need < 2 * SIMG_F * F) need = 2 * SIMG_F * F;                                // S and Q images of the epilogue
@@ -666,6 +666,139 @@ __device__ __forceinline__ void strip_wave(float* simg, float* qimg, unsigned ch
   });
 }
 
+// =====================================================================================================================
+// Round 5: the INTRA step (the pairs inside the two 32-wide blocks of a pair problem, once per sweep) in REGISTERS, one WAVE per
+// block, no barrier and no LDS traffic inside the sets.  Until now it kept the round-2 {S, Q} image in LDS (jacobi_sets: four
+// cells per thread, 32 8-byte LDS accesses per thread and set, conflicted column gathers): 158 us per launch at 64 matrices
+// against 34 us for a cross step (rocprofv3 per-launch trace, profiles/r05_trace_b32.txt) -- a fifth of a sweep for 6 % of its
+// index pairs.
+//   * Ordering: ODD-EVEN TRANSPOSITION with exchange (the "caterpillar" ordering): even sets rotate the position pairs
+//     (0,1)(2,3)..., odd sets (1,2)(3,4)..(29,30); every rotation also EXCHANGES its two positions, so after 32 sets every pair
+//     of the 32 indices has met exactly once (tests/emul checks the cover; NumPy model of the whole sweep: the residual curve
+//     of the round-robin ordering, sweep for sweep).  Partners are always NEIGHBOURS: nothing is re-dealt between sets.
+//   * Layout: lane (a, b) = (lane >> 3, lane & 7) owns S[4a..4a+3][4b..4b+3] and Q[4a..4a+3][4b..4b+3] (rows of Q: original
+//     indices, fixed; columns: positions).  Even sets are lane-local.  In odd sets the pair (4a+3, 4a+4) straddles two lanes:
+//     the column (then the row) on either side is fetched from the neighbour lane (ds_bpermute: the LDS crossbar, no memory)
+//     and each lane computes its own half of the rotation.
+//   * The rotations are derived by the diagonal lanes (a, a) -- two per even set, two per odd set (inner pair and the pair
+//     straddling into lane (a+1, a+1)) -- and broadcast by ds_bpermute.
+//   * A rotation with exchange: position p takes s x_p + c x_q, position q takes c x_p - s x_q ((c, s) of jacobi_rotation,
+//     which annihilates a_pq with x_p' = c x_p - s x_q, x_q' = s x_p + c x_q).  After the 32 sets the positions hold the indices
+//     in reverse order; the images are written in POSITION order -- S_out = Q^T S_in Q holds for the Q that is written, and
+//     nothing downstream depends on which column of a block carries which eigen-direction.
+//   * The off-diagonal block of the pair problem takes no part in the sets: S_AB' = Q_A^T S_AB Q_B by two fp32-MFMA products
+//     afterwards (fused_d), exactly how the tile update treats every other tile of the matrix.
+// Statistics (offmax / offsig) as jacobi_rotation reports them, diagonal lanes only.
+template <int M2>
+__device__ __forceinline__ void intra_wave(float* simg, float* qimg, int h, int lane, float floor_m, float& my_off, float& my_sig) {
+  constexpr int B = M2 / 2;
+  static_assert(B == 32, "8 x 8 lanes of 4 x 4 positions");
+  const int a = lane >> 3, b = lane & 7;
+  const bool diag = a == b;
+  auto bperm = [](int addr, float v) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v))); };
+  const int ad_row = (9 * a) << 2, ad_col = (9 * b) << 2;                        // diagonal lanes of my rows / of my columns
+  const int ad_rowm = (9 * ((a + 7) & 7)) << 2, ad_colm = (9 * ((b + 7) & 7)) << 2;     // ... of the row / column block before mine
+  const int ad_r = ((lane + 1) & 63) << 2, ad_l = ((lane + 63) & 63) << 2;       // lanes (a, b + 1), (a, b - 1)
+  const int ad_d = ((lane + 8) & 63) << 2, ad_u = ((lane + 56) & 63) << 2;       // lanes (a + 1, b), (a - 1, b)
+  const int ad_dd = ((lane + 9) & 63) << 2;                                      // lane (a + 1, b + 1)
+  const bool has_r = b < 7, has_l = b > 0, has_d = a < 7, has_u = a > 0;
+  float S[4][4], Q[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(simg + (h * B + 4 * a + i) * SP + h * B + 4 * b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { S[i][j] = v[j]; Q[i][j] = (diag && i == j) ? 1.f : 0.f; }
+  }
+  // positions (P, P + 1) of this lane, columns: x_P <- s x_P + c x_{P+1}, x_{P+1} <- c x_P - s x_{P+1}
+  auto cols = [&](float (&X)[4][4], int P, float c, float s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float xp = X[i][P], xq = X[i][P + 1];
+      X[i][P] = __builtin_fmaf(s, xp, c * xq);
+      X[i][P + 1] = __builtin_fmaf(c, xp, -(s * xq));
+    }
+  };
+  auto rows = [&](float (&X)[4][4], int P, float c, float s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xp = X[P][j], xq = X[P + 1][j];
+      X[P][j] = __builtin_fmaf(s, xp, c * xq);
+      X[P + 1][j] = __builtin_fmaf(c, xp, -(s * xq));
+    }
+  };
+#pragma unroll 1
+  for (int s2 = 0; s2 < B / 2; ++s2) {
+    {  // ---- even set: pairs (0,1), (2,3) of every lane's rows and columns
+      float c0, s0, c1, s1, o0, g0, o1, g1;
+      jacobi_rotation(S[0][0], S[1][1], S[0][1], floor_m, c0, s0, o0, g0);
+      jacobi_rotation(S[2][2], S[3][3], S[2][3], floor_m, c1, s1, o1, g1);
+      if (diag) { my_off = fmaxf(my_off, fmaxf(o0, o1)); my_sig = fmaxf(my_sig, fmaxf(g0, g1)); }
+      const float cc0 = bperm(ad_col, c0), cs0 = bperm(ad_col, s0), cc1 = bperm(ad_col, c1), cs1 = bperm(ad_col, s1);
+      const float rc0 = bperm(ad_row, c0), rs0 = bperm(ad_row, s0), rc1 = bperm(ad_row, c1), rs1 = bperm(ad_row, s1);
+      cols(S, 0, cc0, cs0); cols(S, 2, cc1, cs1);
+      cols(Q, 0, cc0, cs0); cols(Q, 2, cc1, cs1);
+      rows(S, 0, rc0, rs0); rows(S, 2, rc1, rs1);
+    }
+    {  // ---- odd set: pair (1,2) inside the lane, pair (3, 0') across to the next lane
+      float ci, si, cx, sx, oi, gi, ox, gx;
+      jacobi_rotation(S[1][1], S[2][2], S[1][2], floor_m, ci, si, oi, gi);
+      const float qq = bperm(ad_dd, S[0][0]);          // diagonal lanes: S[4a+4][4a+4] of lane (a+1, a+1)
+      const float pq = bperm(ad_r, S[3][0]);           // ... and S[4a+3][4a+4] of lane (a, a+1)
+      jacobi_rotation(S[3][3], qq, pq, floor_m, cx, sx, ox, gx);
+      if (diag) {
+        my_off = fmaxf(my_off, has_d ? fmaxf(oi, ox) : oi);
+        my_sig = fmaxf(my_sig, has_d ? fmaxf(gi, gx) : gi);
+      }
+      // columns: inner (c, s) and the straddling pair to the right from lane (b, b), the straddling pair to the left from (b-1, b-1)
+      const float cci = bperm(ad_col, ci), csi = bperm(ad_col, si), ccr = bperm(ad_col, cx), csr = bperm(ad_col, sx);
+      const float ccl = bperm(ad_colm, cx), csl = bperm(ad_colm, sx);
+      const float rci = bperm(ad_row, ci), rsi = bperm(ad_row, si), rcd = bperm(ad_row, cx), rsd = bperm(ad_row, sx);
+      const float rcu = bperm(ad_rowm, cx), rsu = bperm(ad_rowm, sx);
+      float nr[4], nl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { nr[i] = bperm(ad_r, S[i][0]); nl[i] = bperm(ad_l, S[i][3]); }
+      cols(S, 1, cci, csi);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x3 = S[i][3], x0 = S[i][0];
+        S[i][3] = has_r ? __builtin_fmaf(csr, x3, ccr * nr[i]) : x3;        // position p of the pair to the right
+        S[i][0] = has_l ? __builtin_fmaf(ccl, nl[i], -(csl * x0)) : x0;     // position q of the pair to the left
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { nr[i] = bperm(ad_r, Q[i][0]); nl[i] = bperm(ad_l, Q[i][3]); }
+      cols(Q, 1, cci, csi);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x3 = Q[i][3], x0 = Q[i][0];
+        Q[i][3] = has_r ? __builtin_fmaf(csr, x3, ccr * nr[i]) : x3;
+        Q[i][0] = has_l ? __builtin_fmaf(ccl, nl[i], -(csl * x0)) : x0;
+      }
+      // rows of S, on the column-rotated values
+      float nd[4], nu[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { nd[j] = bperm(ad_d, S[0][j]); nu[j] = bperm(ad_u, S[3][j]); }
+      rows(S, 1, rci, rsi);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x3 = S[3][j], x0 = S[0][j];
+        S[3][j] = has_d ? __builtin_fmaf(rsd, x3, rcd * nd[j]) : x3;
+        S[0][j] = has_u ? __builtin_fmaf(rcu, nu[j], -(rsu * x0)) : x0;
+      }
+    }
+  }
+  // images in position order: S row-major (pitch SP), Q transposed (QT[column][row]); 16-byte stores
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x4 v = {S[i][0], S[i][1], S[i][2], S[i][3]};
+    *reinterpret_cast<f32x4*>(simg + (h * B + 4 * a + i) * SP + h * B + 4 * b) = v;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 v = {Q[0][j], Q[1][j], Q[2][j], Q[3][j]};
+    *reinterpret_cast<f32x4*>(qimg + (h * B + 4 * b + j) * SP + h * B + 4 * a) = v;
+  }
+}
+
 // D part: the pair problem (bi, bj) of matrix m at outer step p.step_d -- 256 threads (jacobi_fused_d: 1024)
 // LAY: the strip layout (Lay<LAY>::NTD threads per pair problem)
 template <int M2, int LAY>
@@ -683,7 +816,6 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
   float* So = p.Sw + ((size_t)m * npair + g) * FR;
   half_t* Qo16 = p.Qw16 + ((size_t)m * npair + g) * (2 * FR);
   float* Simg = jsm;                               // [M2][M2] floats (cross steps)
-  f32x2* SQ = reinterpret_cast<f32x2*>(jsm);       // [2][M2][M2 + 1] {S, Q} (intra step)
   if (p.first) {
     if (p.st[m].done) return;
     floor_m = p.st[m].floor;
@@ -694,9 +826,10 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       const float v = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
       finite &= fabsf(v) <= 3.0e38f;
       if (r == c) my_dm = fmaxf(my_dm, fabsf(v));
-      if (p.step_d >= 0) Simg[r * SP + c] = v;
-      else { f32x2 w; w[0] = v; w[1] = r == c ? 1.f : 0.f; SQ[r * (M2 + 1) + c] = w; }
+      Simg[r * SP + c] = v;
     }
+    if (p.step_d < 0)                              // intra step: the Q image starts as zero (its diagonal blocks are written after the sets)
+      for (int e = tid; e < SIMG_F; e += NT) jsm[SIMG_F + e] = 0.f;
     __syncthreads();
   } else {
     // ---- look-ahead assembly (cross steps only): the diagonal blocks out of the images D(step_u) left behind, the
@@ -814,7 +947,42 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       else strip_wave<LAY, 2, false>(Simg, Qimg, xb, tid, floor_m, my_off, my_sig);
       JTS(5);
     }
+  } else {
+    // ---- intra step (always the first launch of a segment): waves 0 / 1 diagonalise the two 32 x 32 diagonal blocks in
+    // registers (intra_wave); the off-diagonal block follows by two fp32-MFMA products, S_AB' = Q_A^T S_AB Q_B
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wv < 2) intra_wave<M2>(Simg, Qimg, wv, lane, floor_m, my_off, my_sig);
+    JTS(5);
     __syncthreads();
+    constexpr int WP = B + 4;
+    float* Ws = jsm + 2 * SIMG_F;                   // [B][WP]
+    const int li = lane & 15, lq = lane >> 4;
+    const int ti = (wv >> 1) & 1, tj = wv & 1;      // 16 x 16 tile of the 32 x 32 block (waves 0..3)
+    if (wv < 4) {                                   // W = Q_A^T S_AB: A operand QT rows (the Q image is transposed), B operand rows of S_AB
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < B / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Qimg[(16 * ti + li) * SP + 4 * kk + lq], Simg[(4 * kk + lq) * SP + B + 16 * tj + li], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ws[(16 * ti + 4 * lq + r) * WP + 16 * tj + li] = acc[r];
+    }
+    __syncthreads();
+    if (wv < 4) {                                   // S_AB' = W Q_B, mirrored into S_BA'
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < B / 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Ws[(16 * ti + li) * WP + 4 * kk + lq], Qimg[(B + 16 * tj + li) * SP + B + 4 * kk + lq], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * ti + 4 * lq + r, col = B + 16 * tj + li;
+        Simg[row * SP + col] = acc[r];
+        Simg[col * SP + row] = acc[r];
+        finite &= fabsf(acc[r]) <= 3.0e38f;
+      }
+    }
+  }
+  __syncthreads();
+  {
     constexpr int NCH = M2 / 32;
 #pragma unroll
     for (int i = 0; i < FR / 4 / NT; ++i) {
@@ -829,31 +997,6 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(qcol + qfrag16_k<M2>(cc, l16 >> 4, 0));
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(qcol + qfrag16_k<M2>(cc, l16 >> 4, 4));
       const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      half8 hi, lo;
-      split_f16x8(x, hi, lo);
-      *reinterpret_cast<half8*>(Qo16 + (size_t)f * 8) = part ? lo : hi;
-    }
-  } else {
-    constexpr int PITCH = M2 + 1, KB = (M2 / 2) * (M2 / 2) / NT;
-    float* DO = jsm + 4 * M2 * PITCH;
-    const int cur = jacobi_sets<SWEEP_INTRA, M2, KB>(SQ, DO, tid, floor_m, my_off, my_sig);
-    JTS(5);
-    const f32x2* img = SQ + cur * M2 * PITCH;
-    constexpr int NCH = M2 / 32;
-    for (int e = tid; e < FR; e += NT) So[e] = img[(e / M2) * PITCH + (e % M2)][0];
-#pragma unroll
-    for (int i = 0; i < FR / 4 / NT; ++i) {
-      const int f = tid + i * NT;
-      int qr, qc;
-      qfrag_rc<M2>(f, qr, qc);
-      f32x4 q;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = img[(qr + j) * PITCH + qc][1];
-      *reinterpret_cast<f32x4*>(Qo + (size_t)f * 4) = q;
-      const int l16 = f & 63, part = (f >> 6) & 1, cc = (f >> 7) % NCH, mt = (f >> 7) / NCH;
-      float x[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = img[qfrag16_k<M2>(cc, l16 >> 4, j) * PITCH + 16 * mt + (l16 & 15)][1];
       half8 hi, lo;
       split_f16x8(x, hi, lo);
       *reinterpret_cast<half8*>(Qo16 + (size_t)f * 8) = part ? lo : hi;
