@@ -239,7 +239,9 @@ __device__ __forceinline__ bool refresh_needed(const float* Am, int C, int tid) 
 }
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
+// (round 5: four blocks per CU -- 126 registers with the accumulators in VGPRs, 144 with AGPRs before: the tail's products
+//  3.86 -> 3.81 ms per 32-pair step, bit-identical; a K-stage of 32 instead of 16 loses 0.4 ms: profiles/r05_gemm_variants.txt)
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;       // 32x32 MFMA tiles per wave (2x2 waves)
   constexpr int PA = BM + 4, PB = BN + 4;
   __shared__ __attribute__((aligned(16))) float As[GK * PA];
@@ -1521,9 +1523,15 @@ static JacobiHost* jacobi_host() {
   if (!h.flags) {
     if (hipHostMalloc((void**)&h.flags, 4 * 64 * sizeof(JacobiState)) != hipSuccess) { h.flags = nullptr; return nullptr; }
     bool ok = true;
+    // (tuning builds: WCT_JACOBI_VPRIO = 1 / 2 puts the V-pass streams at the lowest / highest stream priority.  Measured, either
+    //  way: the eigensolver 12.2 -> 22 ms per 32-pair step, nothing at 8 pairs where the V pass does not run -- profiles/r05_vprio.txt)
+    static const int vprio = tune_int("WCT_JACOBI_VPRIO", 0);
+    int prio_lo = 0, prio_hi = 0;
+    if (vprio && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    const int prio = vprio == 1 ? prio_lo : vprio == 2 ? prio_hi : 0;
     for (int g = 0; g < 4 && ok; ++g) {
       ok = hipEventCreateWithFlags(&h.ev[g], hipEventDisableTiming) == hipSuccess &&
-           hipStreamCreateWithFlags(&h.vs[g], hipStreamNonBlocking) == hipSuccess &&
+           (vprio ? hipStreamCreateWithPriority(&h.vs[g], hipStreamNonBlocking, prio) : hipStreamCreateWithFlags(&h.vs[g], hipStreamNonBlocking)) == hipSuccess &&
            hipEventCreateWithFlags(&h.ev_seg[g], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&h.ev_v[g][0], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&h.ev_v[g][1], hipEventDisableTiming) == hipSuccess;
