@@ -1106,7 +1106,12 @@ struct VStripArgs {
 // counter is in order), the barrier makes it everybody's and retires slot (q - 1) % VS_RING, whose refill (tile q + VS_RING - 1)
 // is issued at once.  Past the end of the segment the refills re-fetch the last tile into slots nobody reads: the outstanding
 // count stays constant and so does the wait.
-constexpr int VS_RING = 8;
+// Round 5, last change: a block of the pass used to hold its CU alone (128 KB of ring, 398 registers per lane), and the launch that
+// opens the next segment waited for it (per-launch trace: 86-117 us for that launch against 25-35 alone).  With a ring of FIVE tiles
+// (80 KB) and the fragments of a tile requested one K-chunk ahead instead of all sixteen at once (364 registers) two pair-problem /
+// update blocks fit beside it on every CU: eigensolver 12.05 -> 11.55 ms per 32-pair step, 8.44 -> 7.9 at 16 pairs, frames identical
+// (profiles/r05_vstrip_coresident.txt: rings of 4 / 5 / 6 / 7 / 8 tiles = 11.86 / 11.55 / 11.60 / 11.78 / 11.88).
+constexpr int VS_RING = 5;
 template <int M2, int W>
 constexpr size_t vstrip_lds_bytes() { return (size_t)VS_RING * M2 * M2 * sizeof(float); }
 
@@ -1165,15 +1170,14 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
     const half_t* qb = reinterpret_cast<const half_t*>(vs_ring + (q % VS_RING) * TILE_BYTES);                        \
     f32x4 out[2 * TB];                                                                                               \
     _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};                      \
-    /* ALL fragments of the tile are requested before the first MFMA (round 5: hipcc read them one at a time, each   \
-       ds_read_b128 followed by s_waitcnt lgkmcnt(0) and its MFMAs -- sixteen exposed LDS round trips per pair, and   \
-       the three MFMAs of an accumulator back to back: 100 us of a block's 115).  Per accumulator the order of the    \
-       six products is unchanged (chunk 0: lo.hi, hi.lo, hi.hi; chunk 1 likewise): the same bits. */                \
+    /* The fragments of a K-chunk are requested together, one chunk ahead of the MFMAs that use them (round 5: hipcc \
+       read them one at a time, each ds_read_b128 followed by s_waitcnt lgkmcnt(0) and its MFMAs -- sixteen exposed   \
+       LDS round trips per pair, and the three MFMAs of an accumulator back to back: 100 us of a block's 115).  Per   \
+       accumulator the order of the six products is unchanged (chunk 0: lo.hi, hi.lo, hi.hi; chunk 1 likewise). */   \
     half8 fa[NCH][2 * TB][2];                                                                                        \
-    _Pragma("unroll") for (int c = 0; c < NCH; ++c)                                                                  \
-      _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                          \
-        _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                       \
-          fa[c][mt][part] = *reinterpret_cast<const half8*>(qb + (((mt * NCH + c) * 2 + part) * 64 + lane) * 8);     \
+    _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                            \
+      _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                         \
+        fa[0][mt][part] = *reinterpret_cast<const half8*>(qb + (((mt * NCH + 0) * 2 + part) * 64 + lane) * 8);       \
     if (FRAGS_AHEAD) __builtin_amdgcn_sched_barrier(0);   /* (two waves per SIMD: 256 registers -- let the compiler read just in time) */ \
     half8 bh[NCH], bl[NCH];                                                                                          \
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                                \
@@ -1185,9 +1189,15 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
     }                                                                                                                \
     if (FRAGS_AHEAD) __builtin_amdgcn_sched_barrier(0);                                                              \
     _Pragma("unroll") for (int c = 0; c < NCH; ++c) {                                                                \
+      if (c + 1 < NCH) {                                   /* the next chunk's fragments under this chunk's MFMAs */ \
+        _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt)                                                        \
+          _Pragma("unroll") for (int part = 0; part < 2; ++part)                                                     \
+            fa[c + 1][mt][part] = *reinterpret_cast<const half8*>(qb + (((mt * NCH + c + 1) * 2 + part) * 64 + lane) * 8); \
+      }                                                                                                              \
       _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[c][mt][1], bh[c], out[mt], 0, 0, 0); \
       _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[c][mt][0], bl[c], out[mt], 0, 0, 0); \
       _Pragma("unroll") for (int mt = 0; mt < 2 * TB; ++mt) out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[c][mt][0], bh[c], out[mt], 0, 0, 0); \
+      if (FRAGS_AHEAD) __builtin_amdgcn_sched_barrier(0);                                                            \
     }                                                                                                                \
     if (FRAGS_AHEAD) __builtin_amdgcn_sched_barrier(0);                                                              \
     _Pragma("unroll") for (int t = 0; t < TB; ++t) { v[(pa) * TB + t] = out[t]; v[(pb) * TB + t] = out[TB + t]; }    \
