@@ -510,7 +510,7 @@ def main():
                         'look-ahead launches {pair problems of step s, tile update of step s-1}; from 256 channels on the 64 x 64 pair '
                         'problems are resident in REGISTERS (256 threads, 1 x W strips of cells, rim exchange through LDS, scaled '
                         'rotations: one fma per output, cells as separate S / Q scalars: 60 v_fma per lane and set; four blocks of a launch per CU); V '
-                        'resident in registers per launch segment from 24 matrices per solve on (rotation log by LDS-DMA into a ring of 8 tiles); second-order completion of the '
+                        'resident in registers per launch segment from 24 matrices per solve on (rotation log by LDS-DMA into a ring of 5 tiles; its blocks leave room on their CU for the blocks of the solver); the intra step of a sweep one wave per 32-wide block (odd-even transposition ordering, nothing in LDS during the sets); second-order completion of the '
                         'spectral functions; second-largest time class' % len(LEVELS)}
             line['breakdown_ms_per_step'] = {k: v['ms'] / args.steps for k, v in prof.items()}
         if world == 1 and not args.no_latency and not args.shared_style:
