@@ -113,6 +113,13 @@ int wct_eigh(wct_ctx* ctx, const float* A, int C, int nmat, float* evals, float*
  * Cin and Cout must be multiples of 64 (every 3x3 layer of the path but conv1_1 / the output conv). */
 int wct_conv3x3(wct_ctx* ctx, const float* x, int H, int W, int Cin, const float* w_hwio,
                 const float* bias, int Cout, int relu, int upsample, float* y);
+/* The same layer as the stylize pipeline runs it (Conv2DReflect, ops.py:17-19; cuDNN picks the algorithm for Keras' Conv2D,
+ * vgg_normalised.py:35-40 / model.py:291): a batch x [B][H][W][Cin], fp16 activations out (returned as fp32), optionally with the
+ * following MaxPooling2D(padding='same') fused (vgg_normalised.py:42; needs relu).  algo 0: the kernel the pipeline uses for
+ * this layer shape; 1: the direct implicit-GEMM kernel; 2: the reduced-FLOP kernel (Winograd F(2,3) along y, csrc/conv_wino.hip).
+ * y [B][Ho][Wo][Cout]. */
+int wct_conv3x3_f16(wct_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* w_hwio,
+                    const float* bias, int Cout, int relu, int upsample, int pool, int algo, float* y);
 /* MaxPooling2D(padding='same') (vgg_normalised.py:42): y [(H+1)/2][(W+1)/2][C] */
 int wct_maxpool(wct_ctx* ctx, const float* x, int H, int W, int C, float* y);
 /* encoder to relu<level>_1 (model.py:135-139): img01 [H][W][3] in [0,1]; feat [h][w][C] */

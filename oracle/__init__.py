@@ -16,6 +16,6 @@ Parity status:
 """
 from .wct_oracle import (wct_np, wct_tf, adain, coral_numpy, mat_sqrt_numpy,
                          preserve_colors_np, style_swap, wct_style_swap)
-from .net_oracle import (conv3x3_reflect, maxpool2x2_same, upsample2x_nearest,
+from .net_oracle import (conv3x3_reflect, conv3x3_reflect_wino_f16, maxpool2x2_same, upsample2x_nearest,
                          encode, decode, stylize, preprocess, postprocess,
                          ENCODER_LAYERS, DECODER_ARCHS, decoder_layers)

@@ -85,6 +85,41 @@ def conv3x3_reflect(x, w_hwio, b, relu=True):
     return out
 
 
+_WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float64)
+_WINO_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
+
+
+def conv3x3_reflect_wino_f16(x, w_hwio, b, relu=True):
+    """The SAME layer as conv3x3_reflect with the roundings of the MI355X path's reduced-FLOP kernel (csrc/conv_wino.hip:
+    Winograd F(2,3) along y, direct along x) -- not a reference mode, a restatement that shows accumulation order only:
+    activations rounded to fp16; filters U_f[kx] = sum_ky G[f][ky] g[ky][kx] rounded to fp16; transformed rows T = B^T d
+    computed from the fp16 activations and rounded to fp16 (one add per value); products exact, sums in float64;
+    y(2r) = M0 + M1 + M2, y(2r+1) = M1 - M2 - M3; bias, ReLU; the result rounded to fp16 (the kernel stores fp16)."""
+    x = np.asarray(x, np.float16).astype(np.float64)
+    h, w, cin = x.shape
+    cout = w_hwio.shape[3]
+    he = h + (h & 1)                                     # an odd last row: its partner row is computed and dropped
+    xp = np.pad(x, ((1, 1), (1, 1), (0, 0)), mode='reflect')
+    if he != h:
+        xp = np.concatenate([xp, xp[-1:]], 0)            # (the kernel clamps the row index there; the row only feeds the dropped output)
+    U = np.einsum('fk,kxio->fxio', _WINO_G, np.asarray(w_hwio, np.float64)).astype(np.float32).astype(np.float16).astype(np.float64)
+    rows = [xp[i:i + he:2] for i in range(4)]            # padded row 2r + i of every pair-row r
+    y = np.empty((he, w, cout), np.float64)
+    M = []
+    for f in range(4):
+        T = sum(_WINO_BT[f, i] * rows[i] for i in range(4)).astype(np.float16).astype(np.float64)    # [he/2][w+2][cin]
+        m = 0
+        for kx in range(3):
+            m = m + T[:, kx:kx + w, :].reshape(-1, cin) @ U[f, kx]
+        M.append(m.reshape(he // 2, w, cout))
+    y[0::2] = (M[0] + M[1]) + M[2]
+    y[1::2] = (M[1] - M[2]) - M[3]
+    y = y[:h] + np.asarray(b, np.float64)
+    if relu:
+        y = np.maximum(y, 0)
+    return y.astype(np.float16).astype(np.float32)
+
+
 def conv1x1(x, w_hwio, b):
     """The VGG 'preprocess' 1x1 conv (vgg_normalised.py:25-26,28-38)."""
     cin = w_hwio.shape[2]

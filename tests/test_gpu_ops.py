@@ -412,6 +412,68 @@ def test_conv3x3(ctx, h, w, cin, cout, relu, up):
     assert e32 < 3e-3
 
 
+@pytest.mark.parametrize('h,w,cin,cout,relu,up,pool,batch', [
+    (32, 32, 256, 256, True, False, False, 1),      # 16 x 16 tiles x 128 channels
+    (64, 48, 256, 256, True, False, True, 2),       # fused 'same' max-pool (conv3_4), a batch
+    (37, 29, 256, 256, True, False, False, 1),      # ragged edges, odd height: a pair-row with one row inside
+    (37, 29, 256, 256, True, False, True, 1),       # ... pooled in ceil mode
+    (16, 16, 512, 512, True, False, False, 1),      # deep K, small grid: the 8-row tiles
+    (20, 12, 256, 256, False, True, False, 1),      # upsample folded into the loader, no ReLU
+    (48, 80, 512, 256, True, False, False, 1),      # decoder's 512 -> 256
+    (24, 40, 64, 64, True, False, False, 1),        # a shape the policy leaves on the direct kernel (algo 2 packs for the call)
+    (40, 24, 128, 192, True, True, False, 2),       # 64-channel blocks
+])
+def test_conv3x3_reduced_flop_kernel(ctx, h, w, cin, cout, relu, up, pool, batch):
+    """csrc/conv_wino.hip (Winograd F(2,3) along y, direct along x) against (a) the restatement with ITS roundings
+    (fp16 filters U = G g, fp16 transformed rows, fp16 output): what is left is accumulation order and fp16 rounding flips;
+    (b) the fp32 oracle: the per-layer gate of 1.5e-3 (measured on the CPU first, profiles/r06_winograd_error.txt);
+    (c) the direct kernel through the same entry point, whose bits must be the round-5 path's."""
+    rng = np.random.default_rng(h * 1000 + cin + 7 * pool)
+    x = np.maximum(rng.standard_normal((batch, h, w, cin)), 0).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    got = ctx.conv3x3_f16(x, wt, b, relu=relu, upsample=up, pool=pool, algo=2)
+    direct = ctx.conv3x3_f16(x, wt, b, relu=relu, upsample=up, pool=pool, algo=1)
+    for i in range(batch):
+        xin = oracle.upsample2x_nearest(x[i]) if up else x[i]
+        emu = oracle.conv3x3_reflect_wino_f16(xin, wt, b, relu)
+        want32 = oracle.conv3x3_reflect(_h(xin), wt, b, relu)
+        old = _h(ctx.conv3x3(x[i], wt, b, relu=relu, upsample=up))
+        if pool:
+            emu, want32, old = oracle.maxpool2x2_same(emu), oracle.maxpool2x2_same(want32), oracle.maxpool2x2_same(old)
+        assert got[i].shape == want32.shape
+        e_emu, e32, e_dir = rel_err(got[i], emu), rel_err(got[i], want32), rel_err(direct[i], want32)
+        print('wino %dx%d %d->%d up=%d pool=%d: vs its own roundings %.2e, vs fp32 %.2e (direct kernel %.2e)' % (h, w, cin, cout, up, pool, e_emu, e32, e_dir))
+        assert e_emu < 1e-4 and max_rel(got[i], emu) < 2e-3          # (one fp16 ulp of the largest value: a rounding flip)
+        assert e32 < 1.5e-3
+        assert np.array_equal(direct[i], old)                      # algo 1 == wct_conv3x3's kernel, rounded to fp16
+
+
+def test_conv3x3_pipeline_choice_is_by_layer_shape(ctx):
+    """algo 0 (what run_encoder / run_decoder launch) takes the reduced-FLOP kernel for the >= 256-channel layers and the direct
+    one below, whatever the batch or the image size: a frame must not depend on the batch it is computed in."""
+    rng = np.random.default_rng(11)
+    for cin, cout, wide in [(256, 256, True), (512, 512, True), (512, 256, True), (128, 256, False), (256, 128, False), (64, 64, False)]:
+        wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+        b = np.zeros(cout, np.float32)
+        for batch, h, w in [(1, 16, 16), (3, 32, 48)]:
+            x = np.maximum(rng.standard_normal((batch, h, w, cin)), 0).astype(np.float32)
+            y0 = ctx.conv3x3_f16(x, wt, b, algo=0)
+            assert np.array_equal(y0, ctx.conv3x3_f16(x, wt, b, algo=2 if wide else 1)), (cin, cout, batch)
+            assert np.array_equal(y0[0], ctx.conv3x3_f16(x[0], wt, b, algo=0))        # batch == single image
+    # the three tile shapes of the reduced-FLOP kernel (picked from the grid size: 8 / 4 / 1 images of 64 x 64 at 256 -> 256 take
+    # <16,128,2,2> / <16,64,2,2> / <8,64,2,2>) accumulate in the same order: the same bits
+    wt = (rng.standard_normal((3, 3, 256, 256)) * np.sqrt(2.0 / (9 * 256))).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32) * 0.1
+    x = np.maximum(rng.standard_normal((8, 64, 64, 256)), 0).astype(np.float32)
+    y8 = ctx.conv3x3_f16(x, wt, b, algo=0)
+    assert np.array_equal(y8[:4], ctx.conv3x3_f16(x[:4], wt, b, algo=0))
+    assert np.array_equal(y8[0], ctx.conv3x3_f16(x[0], wt, b, algo=0))
+    y8p = ctx.conv3x3_f16(x, wt, b, pool=True, algo=0)
+    assert np.array_equal(y8p[0], ctx.conv3x3_f16(x[0], wt, b, pool=True, algo=0))
+    assert np.array_equal(y8p[0], oracle.maxpool2x2_same(y8[0]))
+
+
 def test_maxpool(ctx):
     rng = np.random.default_rng(3)
     for h, w, c in [(8, 8, 64), (9, 7, 128), (1, 5, 8)]:

@@ -34,6 +34,7 @@ SIGNATURES = [
     ('wct_set_style_swap', C.c_int, [_P, C.c_float, C.c_int, C.c_int]),
     ('wct_eigh', C.c_int, [_P, _F, C.c_int, C.c_int, _F, _F, _I]),
     ('wct_conv3x3', C.c_int, [_P, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.c_int, C.c_int, C.c_int, _F]),
+    ('wct_conv3x3_f16', C.c_int, [_P, _F, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     ('wct_maxpool', C.c_int, [_P, _F, C.c_int, C.c_int, C.c_int, _F]),
     ('wct_encode', C.c_int, [_P, _F, C.c_int, C.c_int, C.c_int, _F]),
     ('wct_decode', C.c_int, [_P, _F, C.c_int, C.c_int, C.c_int, _F]),

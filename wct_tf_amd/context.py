@@ -146,6 +146,26 @@ class Context(object):
         check(self.lib.wct_conv3x3(self.h, fptr(x), h, wd, cin, fptr(w), fptr(b), cout, int(relu), int(upsample), fptr(y)))
         return y
 
+    def conv3x3_f16(self, x, w_hwio, bias, relu=True, upsample=False, pool=False, algo=0):
+        """One 3x3 layer as the stylize pipeline runs it (fp16 activations out, optional fused 'same' max-pool) on a batch
+        x [B][H][W][Cin] (or [H][W][Cin]); algo 0 = the pipeline's kernel for this shape, 1 = direct, 2 = Winograd F(2,3)."""
+        x = f32(x)
+        single = x.ndim == 3
+        if single:
+            x = x[None]
+        w = f32(w_hwio)
+        b = f32(bias)
+        n, h, wd, cin = x.shape
+        cout = w.shape[3]
+        s = 2 if upsample else 1
+        ho, wo = h * s, wd * s
+        if pool:
+            ho, wo = (ho + 1) // 2, (wo + 1) // 2
+        y = np.empty((n, ho, wo, cout), np.float32)
+        check(self.lib.wct_conv3x3_f16(self.h, fptr(x), n, h, wd, cin, fptr(w), fptr(b), cout, int(relu), int(upsample), int(pool),
+                                       int(algo), fptr(y)))
+        return y[0] if single else y
+
     def maxpool(self, x):
         x = f32(x)
         h, w, c = x.shape

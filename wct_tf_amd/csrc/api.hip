@@ -33,6 +33,7 @@ struct DevBuf {
 struct ConvLayer {
   half_t* w = nullptr;   // [cout][9][cin]
   float* b = nullptr;
+  half_t* ww = nullptr;  // the filters transformed for conv_wino.hip (ConvArgs::w_wino), or null: the direct kernel only
   int cin = 0, cout = 0;
 };
 
@@ -78,6 +79,7 @@ struct wct_ctx {
   float ss_alpha = 0.6f;           // style-swap settings (stylize.py:34-37 defaults)
   int ss_patch = 3, ss_stride = 1;
   bool prof = false;
+  bool no_wino = false;            // the training forward keeps every layer on the direct kernel (its backward assumes it)
   std::vector<ProfRec> recs;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
   double prof_ms[WCT_PROF_CLASSES] = {0};
@@ -171,6 +173,7 @@ extern "C" int wct_create(int device, wct_ctx** out) {
 static void free_layer(ConvLayer& l) {
   if (l.w) hipFree(l.w);
   if (l.b) hipFree(l.b);
+  if (l.ww) hipFree(l.ww);
   l = ConvLayer();
 }
 static void free_decoder(Decoder& d) {
@@ -340,6 +343,16 @@ static int upload(wct_ctx* c, const void* host, size_t bytes, void** dev) {
   return WCT_OK;
 }
 
+// Which layers also get their filters packed for the reduced-FLOP kernel (conv_wino.hip).  Decided by the layer's channel counts
+// alone -- never by the batch or the image size: a frame must not depend on the batch it is computed in.  WCT_WINOGRAD=0 is a TEST
+// hook (read once per process, like WCT_FUSE_CONV1): every layer on the direct kernel, the round-5 bits.  A -DWCT_TUNING build
+// takes the channel threshold from WCT_WINO_MIN.
+static bool wino_layer(int cin, int cout) {
+  static const int on = getenv("WCT_WINOGRAD") ? atoi(getenv("WCT_WINOGRAD")) : 1;
+  static const int min_ch = tune_int("WCT_WINO_MIN", 256);
+  return on && cin >= min_ch && cout >= min_ch && cin % 64 == 0 && cout % 64 == 0;
+}
+
 // HWIO fp32 -> fp16 MFMA A-fragments [cout/32][tap][cin/16][lane][8]: lane l of a fragment holds output
 // channel 32*T + (l & 31), input channels 16*k16 + 8*(l >> 5) .. +7 (the v_mfma_f32_32x32x16_f16 A layout),
 // so a wave fetches a fragment with ONE fully coalesced 1-KiB load
@@ -357,6 +370,23 @@ static int pack_conv(wct_ctx* c, const float* w_hwio, const float* b, int cin, i
   TRY(upload(c, packed.data(), packed.size() * sizeof(half_t), (void**)&out->w));
   TRY(upload(c, b, (size_t)cout * sizeof(float), (void**)&out->b));
   out->cin = cin; out->cout = cout;
+  if (wino_layer(cin, cout)) {
+    // U_f[kx] = sum_ky G[f][ky] g[ky][kx] (Winograd F(2,3) along y), in double, rounded to fp16 once; fragments
+    // [cout/32][f*3+kx][cin/16][lane][8] like the direct ones
+    static const double G[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    std::vector<half_t> pw((size_t)cout * 12 * cin);
+    for (int f = 0; f < 4; ++f)
+      for (int kx = 0; kx < 3; ++kx)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) {
+            double u = 0;
+            for (int ky = 0; ky < 3; ++ky) u += G[f][ky] * (double)w_hwio[((size_t)(ky * 3 + kx) * cin + ci) * cout + co];
+            const int lane = (co & 31) + 32 * ((ci >> 3) & 1);
+            const size_t frag = ((size_t)(co >> 5) * 12 + f * 3 + kx) * c16 + (ci >> 4);
+            pw[(frag * 64 + lane) * 8 + (ci & 7)] = (half_t)(float)u;
+          }
+    TRY(upload(c, pw.data(), pw.size() * sizeof(half_t), (void**)&out->ww));
+  }
   return WCT_OK;
 }
 
@@ -503,6 +533,7 @@ static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16
                     int B, int H, int W, int upsample, int relu, int pool = 0, float* usum = nullptr, unsigned* umax = nullptr) {
   ConvArgs a;
   a.x = x; a.w = l.w; a.bias = l.b; a.y16 = y16; a.y32 = y32; a.usum = usum; a.umax = umax;
+  a.w_wino = c->no_wino ? nullptr : l.ww;
   a.B = B; a.H = H; a.W = W; a.Cin = l.cin; a.Cout = l.cout; a.upsample = upsample; a.relu = relu; a.pool = pool;
   const double px = (double)B * H * W;
   const double in_px = upsample ? px / 4 : px;
@@ -760,6 +791,56 @@ extern "C" int wct_conv3x3(wct_ctx* c, const float* x, int H, int W, int Cin, co
   if (!rc) rc = launch_f32_to_f16((float*)dx, (half_t*)c->stage[1].p, (size_t)H * W * Cin, c->stream);
   if (!rc) rc = run_conv(c, l, (half_t*)c->stage[1].p, nullptr, (float*)c->stage[2].p, 1, Ho, Wo, upsample, relu);
   if (!rc) rc = fetch(c, y, c->stage[2].p, (size_t)Ho * Wo * Cout * 4);
+  hipStreamSynchronize(c->stream);
+  free_layer(l);
+  return rc;
+}
+
+// One layer as the PIPELINE runs it: fp16 activations in, fp16 out (returned as fp32), optionally with the fused 2x2 'same'
+// max-pool.  algo 0: the pipeline's choice for this layer shape, 1: the direct kernel, 2: the reduced-FLOP kernel (conv_wino.hip;
+// an error if the shape is not one it takes).  x: [B][H][W][Cin] fp32 (rounded to fp16 on the device like wct_conv3x3).
+extern "C" int wct_conv3x3_f16(wct_ctx* c, const float* x, int B, int H, int W, int Cin, const float* w_hwio, const float* bias,
+                               int Cout, int relu, int upsample, int pool, int algo, float* y) {
+  ARG_CHECK(c && x && w_hwio && bias && y && B >= 1 && algo >= 0 && algo <= 2);
+  HIP_TRY(hipSetDevice(c->device));
+  const int Hc = upsample ? 2 * H : H, Wc = upsample ? 2 * W : W;
+  const int Ho = pool ? (Hc + 1) / 2 : Hc, Wo = pool ? (Wc + 1) / 2 : Wc;
+  ConvLayer l;
+  TRY(pack_conv(c, w_hwio, bias, Cin, Cout, &l));
+  int rc = WCT_OK;
+  if (algo == 2 && !l.ww) {
+    // a shape the policy leaves on the direct kernel: pack its Winograd fragments on the device for this call
+    float* w32 = nullptr;
+    rc = upload(c, w_hwio, (size_t)9 * Cin * Cout * sizeof(float), (void**)&w32);
+    if (!rc && hipMalloc((void**)&l.ww, (size_t)Cout * 12 * Cin * sizeof(half_t)) != hipSuccess) { wct_set_error("hipMalloc failed"); rc = WCT_ERR_NOMEM; }
+    if (!rc) rc = launch_pack_conv_wino_frag(w32, l.ww, Cin, Cout, c->stream);
+    hipStreamSynchronize(c->stream);
+    if (w32) hipFree(w32);
+  }
+  const bool keep = c->no_wino;
+  c->no_wino = algo == 1;
+  void* dx;
+  const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Ho * Wo * Cout;
+  if (!rc) rc = stage_in(c, 0, x, nin * 4, &dx);
+  if (!rc) rc = ensure(c, c->stage[1], nin * 2);
+  if (!rc) rc = ensure(c, c->stage[2], nout * 2);
+  if (!rc) rc = ensure(c, c->stage[3], nout * 4);
+  if (!rc) rc = launch_f32_to_f16((float*)dx, (half_t*)c->stage[1].p, nin, c->stream);
+  if (!rc) {
+    ConvArgs a;
+    a.x = (half_t*)c->stage[1].p; a.w = l.w; a.bias = l.b; a.y16 = (half_t*)c->stage[2].p; a.y32 = nullptr; a.usum = nullptr; a.umax = nullptr;
+    a.B = B; a.H = Hc; a.W = Wc; a.Cin = Cin; a.Cout = Cout; a.upsample = upsample; a.relu = relu; a.pool = pool;
+    a.w_wino = c->no_wino ? nullptr : l.ww;
+    if (algo == 2 && !conv3x3_wino_takes(a)) { wct_set_error("wct_conv3x3_f16: algo 2 does not take this layer"); rc = WCT_ERR_ARG; }
+    if (!rc) {
+      const double px = (double)B * Hc * Wc;
+      ProfScope ps(c, 0, 2.0 * px * 9 * Cin * Cout, (double)nin * 2 + (double)nout * 2 + 9.0 * Cin * Cout * 2);
+      rc = launch_conv3x3(a, c->stream);
+    }
+  }
+  c->no_wino = keep;
+  if (!rc) rc = launch_f16_to_f32((half_t*)c->stage[2].p, (float*)c->stage[3].p, nout, c->stream);
+  if (!rc) rc = fetch(c, y, c->stage[3].p, nout * 4);
   hipStreamSynchronize(c->stream);
   free_layer(l);
   return rc;
@@ -1045,6 +1126,7 @@ static int apply_adam(wct_ctx* c, Decoder& d, float lr, float beta1, float beta2
     } else {
       ConvLayer& l = d.convs[ci++];
       TRY(launch_pack_conv_frag(d.w32[i], l.w, l.cin, l.cout, s));
+      if (l.ww) TRY(launch_pack_conv_wino_frag(d.w32[i], l.ww, l.cin, l.cout, s));
       HIP_TRY(hipMemcpyAsync(l.b, d.b32[i], (size_t)l.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
   }
@@ -1059,6 +1141,9 @@ extern "C" int wct_train_step(wct_ctx* c, int level, const float* images, int B,
   ARG_CHECK(c && images && losses_out && level >= 1 && level <= 5 && B >= 1 && B <= 64 && step >= 1);
   HIP_TRY(hipSetDevice(c->device));
   if (!c->enc_loaded) { wct_set_error("encoder weights not set (wct_set_encoder)"); return WCT_ERR_STATE; }
+  // every forward layer of a training step on the direct kernel: the backward pass differentiates THAT arithmetic (fp16-rounded
+  // operands, exact products), and the gradient tests hold it to 1e-4
+  struct DirectOnly { wct_ctx* c; DirectOnly(wct_ctx* x) : c(x) { c->no_wino = true; } ~DirectOnly() { c->no_wino = false; } } direct_only(c);
   Decoder& d = c->dec[level];
   if (!d.loaded) { wct_set_error("decoder weights for relu%d_1 not set (wct_set_decoder)", level); return WCT_ERR_STATE; }
   const int scale = 1 << (level - 1);

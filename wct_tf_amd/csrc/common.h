@@ -82,6 +82,9 @@ struct ConvArgs {
   const half_t* w1frag = nullptr;
   const float* bias1 = nullptr;
   int clamp01 = 0;
+  // the layer's filters transformed for the reduced-FLOP kernel (conv_wino.hip): fp16 MFMA A-fragments
+  // [Cout/32][f*3+kx][Cin/16][lane][8] of U_f[kx] = sum_ky G[f][ky] g[ky][kx].  null: the direct kernel only.
+  const half_t* w_wino = nullptr;
 };
 // The maxima of an image are merged into UMAX_SLOTS words (two cache lines) instead of one: tens of thousands of
 // wavefronts bumping ONE word -- or 32 words of one cache line -- serialise in a single L2 channel (measured: +94 us per
@@ -97,6 +100,9 @@ __device__ __forceinline__ void umax_merge(unsigned* umax_img, int slot, float v
   }
 }
 int launch_conv3x3(const ConvArgs& a, hipStream_t s);
+// conv_wino.hip: Winograd F(2,3) along y x direct along x -- 12 MFMA products per 2 outputs instead of 18 (fp16 output only)
+bool conv3x3_wino_takes(const ConvArgs& a);
+int launch_conv3x3_wino(const ConvArgs& a, hipStream_t s);
 
 struct ConvFirstArgs {   // 3 -> 64 with the 1x1 'preprocess' folded in
   const float* x;      // [B][H][W][3] fp32 image in [0,1]
@@ -236,6 +242,7 @@ int launch_bias_grad(const float* g, size_t rows, int C, float* partial, float* 
 int launch_reduce_slabs(const float* partial, size_t n, int nslab, float* out, hipStream_t s);
 int launch_adam(float* w, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2, float eps, hipStream_t s);
 int launch_pack_conv_frag(const float* w, half_t* frag, int cin, int cout, hipStream_t s);
+int launch_pack_conv_wino_frag(const float* w, half_t* frag, int cin, int cout, hipStream_t s);
 int launch_pack_last_frag(const float* w, half_t* frag, hipStream_t s);
 int launch_transpose_w(const float* w, float* wt, int cin, int cout, int cout_pad, hipStream_t s);
 int launch_pad3to4(const float* x, float* y, size_t n, hipStream_t s);

@@ -744,6 +744,8 @@ int launch_conv3x3(const ConvArgs& a, hipStream_t s) {
   ARG_CHECK((size_t)a.H * a.W * a.Cout * (a.y32 ? 4 : 2) < ((size_t)1 << 31));     // per-image output buffers (epilogue)
   ARG_CHECK(!a.usum || (a.y32 && a.umax && a.relu && a.W % 16 == 0));
   ARG_CHECK(!a.pool || (a.relu && !a.y32));            // the fused pool relies on post-ReLU values (>= 0) at ragged edges
+  // the reduced-FLOP kernel, where the caller packed its filters for it (api.hip: the wide layers) and the epilogue is one it has
+  if (conv3x3_wino_takes(a)) return launch_conv3x3_wino(a, s);
   // pick the largest tile that still gives the chip >= ~2 blocks per CU (two are resident per CU)
   if (a.img1) {                                           // conv1_1 inside the patch loader: the 512-pixel x 64-channel block only
     ARG_CHECK(a.Cin == 64 && a.Cout == 64 && !a.upsample && a.w1frag && a.bias1);

@@ -318,6 +318,25 @@ __global__ void pack_conv_frag_kernel(const float* w, half_t* frag, int cin, int
     frag[i] = (half_t)w[((size_t)tap * cin + ci) * cout + co];
   }
 }
+// fp32 HWIO -> the Winograd fragments of conv_wino.hip, [cout/32][f*3+kx][cin/16][lane][8] of U_f[kx] = sum_ky G[f][ky] g[ky][kx]
+// (api.hip::pack_conv computes the same values on the host: the sum in double, one rounding to fp16)
+__global__ void pack_conv_wino_frag_kernel(const float* w, half_t* frag, int cin, int cout) {
+  const size_t total = (size_t)cout * 12 * cin;
+  const int c16 = cin / 16;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    size_t fr = i >> 9;                                 // fragment index ((T*12 + f*3 + kx)*c16 + k16)
+    const int k16 = (int)(fr % c16); fr /= c16;
+    const int t12 = (int)(fr % 12);
+    const int T = (int)(fr / 12);
+    const int f = t12 / 3, kx = t12 % 3;
+    const int co = T * 32 + (lane & 31), ci = k16 * 16 + (lane >> 5) * 8 + j;
+    const double g0 = w[((size_t)(0 * 3 + kx) * cin + ci) * cout + co], g1 = w[((size_t)(1 * 3 + kx) * cin + ci) * cout + co],
+                 g2 = w[((size_t)(2 * 3 + kx) * cin + ci) * cout + co];
+    const double u = f == 0 ? g0 : f == 1 ? 0.5 * g0 + 0.5 * g1 + 0.5 * g2 : f == 2 ? 0.5 * g0 - 0.5 * g1 + 0.5 * g2 : g2;
+    frag[i] = (half_t)(float)u;
+  }
+}
 // 64 -> 3 output conv: A-fragments [k-step 4][lane][8] with row tap*3+co (27 of 32), see ConvLastArgs
 __global__ void pack_last_frag_kernel(const float* w, half_t* frag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,6 +372,12 @@ int launch_pad3to4(const float* x, float* y, size_t n, hipStream_t s) {
 int launch_pack_conv_frag(const float* w, half_t* frag, int cin, int cout, hipStream_t s) {
   ARG_CHECK(cin % 16 == 0 && cout % 32 == 0);
   hipLaunchKernelGGL(pack_conv_frag_kernel, dim3(tr_blocks((size_t)cout * 9 * cin)), dim3(256), 0, s, w, frag, cin, cout);
+  HIP_TRY(hipGetLastError());
+  return WCT_OK;
+}
+int launch_pack_conv_wino_frag(const float* w, half_t* frag, int cin, int cout, hipStream_t s) {
+  ARG_CHECK(cin % 16 == 0 && cout % 32 == 0);
+  hipLaunchKernelGGL(pack_conv_wino_frag_kernel, dim3(tr_blocks((size_t)cout * 12 * cin)), dim3(256), 0, s, w, frag, cin, cout);
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
