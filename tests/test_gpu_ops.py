@@ -462,7 +462,7 @@ def test_conv3x3_pipeline_choice_is_by_layer_shape(ctx):
             assert np.array_equal(y0, ctx.conv3x3_f16(x, wt, b, algo=2 if wide else 1)), (cin, cout, batch)
             assert np.array_equal(y0[0], ctx.conv3x3_f16(x[0], wt, b, algo=0))        # batch == single image
     # the three tile shapes of the reduced-FLOP kernel (picked from the grid size: 8 / 4 / 1 images of 64 x 64 at 256 -> 256 take
-    # <16,128,2,2> / <16,64,2,2> / <8,64,2,2>) accumulate in the same order: the same bits
+    # <16,128,1,4, interleaved> / <8,128,1,4> / <8,64,2,2>) accumulate in the same order: the same bits
     wt = (rng.standard_normal((3, 3, 256, 256)) * np.sqrt(2.0 / (9 * 256))).astype(np.float32)
     b = rng.standard_normal(256).astype(np.float32) * 0.1
     x = np.maximum(rng.standard_normal((8, 64, 64, 256)), 0).astype(np.float32)

@@ -15,7 +15,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-val
 # WCT_BUILD_TUNING=1 (experiments on the GPU box, tools/): compile the A-B / tuning switches in (-DWCT_TUNING: they are read
 # from the environment); the product build has them as constants (csrc/common.h)
 if os.environ.get('WCT_BUILD_TUNING'):
-    FLAGS = FLAGS + ['-DWCT_TUNING']
+    FLAGS = FLAGS + ['-DWCT_TUNING'] + os.environ.get('WCT_BUILD_DEFS', '').split()      # (extra -D switches of an experiment)
 # per-file additions.  wct.hip: the SLP vectoriser packs the eigensolver's rotation arithmetic into v_pk_fma_f32 pairs at the
 # price of ~20 v_mov per rotation set for operand assembly (measured: Jacobi 25.2 -> 23.8 ms per 32-pair step without it)
 FILE_FLAGS = {'wct.hip': ['-fno-slp-vectorize']}

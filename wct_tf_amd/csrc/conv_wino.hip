@@ -23,13 +23,35 @@
 // B = pixels, one ds_read_b128 per fragment a tap ahead; a wave owns MT pixel tiles (2 pair-rows x 16 columns) x NT channel tiles
 // x 4 row frequencies.  One LDS-only barrier per K-chunk (s_waitcnt lgkmcnt(0) + s_barrier: the weight loads stay in flight).
 #include "common.h"
+#include <algorithm>
 
+#include <stdio.h>
 namespace {
+// Phase timing build (-DWINO_TS): lane 0 of every wave stamps s_memtime at its phase boundaries; the launcher prints the means.
+#ifdef WINO_TS
+__device__ unsigned long long wino_ts[8192 * 4 * 8];
+#define WTS(slot) do { if ((threadIdx.x & 63) == 0) { const unsigned fl_ = blockIdx.x + gridDim.x * blockIdx.y; if (fl_ < 8192) wino_ts[(fl_ * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define WTS(slot) do {} while (0)
+#endif
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 constexpr int TW = 16;          // tile width in pixels
 constexpr int PITCH = 20;       // patch row pitch in pixels (18 used)
 constexpr int BK = 32;          // input channels per K-chunk
+
+// a - b on eight packed fp16 values: v_pk_add_f16 with the neg modifiers on the second operand (hipcc expands the vector
+// subtraction into v_sub_f16 + v_sub_f16_sdwa + v_pack_b32_f16 per pair: three instructions for one)
+__device__ __forceinline__ half8 pk_sub(half8 a, half8 b) {
+  u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b), r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned o;
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(ua[i]), "v"(ub[i]));
+    r[i] = o;
+  }
+  return __builtin_bit_cast(half8, r);
+}
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {      // 1-px REFLECT padding; ragged tiles clamp (masked at the store)
   if (i < 0) i = -i;
@@ -38,20 +60,31 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {      // 1-px REFLECT 
   return i >= n ? n - 1 : i;
 }
 
-template <int TH, int BN, int WM, int WN>
+// IL: the schedule for ONE wave per SIMD (the 16-row tiles: 256 accumulator registers per lane in AGPRs).  Nothing but the wave's
+// own instruction order hides a latency there, so every MFMA is followed by its share of the tap's other work in SOURCE order,
+// pinned by a sched_barrier: the weight loads of tap t + 3, the pixel reads of tap t + 1, and the staging of the next chunk's
+// patch spread over the taps (raw rows requested slot by slot at taps 2.., transformed and parked slot by slot at taps 7.., one
+// barrier after tap 10) -- no branch in the loop body: the last chunk stages a patch nobody reads.
+template <int TH, int BN, int WM, int WN, bool IL>
 __global__ __launch_bounds__(256, TH >= 16 ? 1 : 2)
-void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
+void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles, int dbg_arg) {
+#ifdef WCT_TUNING
+  const int dbg = dbg_arg;      // ablation switches (tuning builds, WCT_WINO_DBG): 1 no weight loads, 2 no patch staging, 4 no MFMAs, 8 no fragment reads, 16 no epilogue
+#else
+  constexpr int dbg = 0;
+#endif
   constexpr int PR = TH / 2;                 // pair-rows of the tile
   constexpr int MT = (PR / 2) / WM;          // MFMA pixel tiles (2 pair-rows x 16 columns) per wave
   constexpr int NT = (BN / 32) / WN;
   constexpr int G = 256 / PR;                // loader threads per pair-row
   constexpr int SL = (72 + G - 1) / G;       // (pixel, piece) slots per loader thread: 18 x 4 per pair-row
   constexpr int PATCH_BYTES = PR * 4 * PITCH * 64;
-  constexpr int BIAS_OFF = 2 * PATCH_BYTES;
+  constexpr int DUMP_OFF = 2 * PATCH_BYTES;  // IL: where the idle lanes of the last loader slot put their four pieces (8 KB)
   constexpr int PF_TAP = 5;                  // tap at which the next chunk's raw rows are requested; they are parked at tap 10
   static_assert(PR % 2 == 0 && (PR / 2) % WM == 0 && 256 % PR == 0 && WM * WN == 4, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  WTS(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   int bid = blockIdx.x;
@@ -86,6 +119,7 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
     if (p.upsample) ix >>= 1;
     col_off[j] = (unsigned)(ix * p.Cin + piece * 8) * 2;
     dst_off[j] = ((lpr * 4 * PITCH + px) * 4 + (piece ^ ((px >> 2) & 3))) * 16;
+    if (IL && !slot_ok[j]) dst_off[j] = DUMP_OFF + tid * 16;        // (no exec-mask branch in the interleaved loop)
   }
   u32x4 raw[SL][4];
   auto load_rows = [&](int chunk) {
@@ -100,7 +134,7 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
     for (int j = 0; j < SL; ++j) {
       const half8 d0 = __builtin_bit_cast(half8, raw[j][0]), d1 = __builtin_bit_cast(half8, raw[j][1]);
       const half8 d2 = __builtin_bit_cast(half8, raw[j][2]), d3 = __builtin_bit_cast(half8, raw[j][3]);
-      const half8 t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3;
+      const half8 t0 = pk_sub(d0, d2), t1 = d1 + d2, t2 = pk_sub(d2, d1), t3 = pk_sub(d1, d3);
       if (slot_ok[j]) {
         unsigned char* d = smem + buf * PATCH_BYTES + dst_off[j];
         *reinterpret_cast<half8*>(d) = t0;
@@ -126,21 +160,25 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) wfrag[nt] = (((n0 >> 5) + wn * NT + nt) * 12 * c16 * 512 + lane * 8) * 2;
 
-  if (tid < BN / 4) *reinterpret_cast<f32x4*>(smem + BIAS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.bias + n0 + tid * 4);
-
+  // the bias rides in M1, the one frequency that enters both output rows with +1 (y(2r) = M0 + M1 + M2, y(2r+1) = M1 - M2 - M3):
+  // acc register r of a tile holds channel (r & 3) + 8 (r >> 2) + 4 kgrp
   f32x16 acc[4][NT][MT];
 #pragma unroll
-  for (int f = 0; f < 4; ++f)
+  for (int nt = 0; nt < NT; ++nt) {
+    f32x4 bv[4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int rq = 0; rq < 4; ++rq) bv[rq] = *reinterpret_cast<const f32x4*>(p.bias + n0 + (wn * NT + nt) * 32 + 8 * rq + 4 * kgrp);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][nt][mt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[f][nt][mt][r] = f == 1 ? bv[r >> 2][r & 3] : 0.f;
+  }
 
   const int n_chunks = p.Cin / BK;             // even
   half8 wf[3][NT][2];                          // weight fragments of three taps: in use, next, the one after
-  half8 bf[2][2][MT];                          // pixel fragments of two taps (both k-steps)
+  half8 bf[IL ? 3 : 2][2][MT];                 // pixel fragments of two taps (both k-steps); IL: three -- read two taps ahead
   auto load_w = [&](half8 (&dst)[NT][2], int tap12, int chunk) {
     const int soff = (tap12 * c16 + chunk * 2) * 1024;          // uniform
 #pragma unroll
@@ -157,6 +195,93 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
         dst[ks][mt] = *reinterpret_cast<const half8*>(smem + buf * PATCH_BYTES + rd_base[kx][ks] + (mt * 8 + f) * PITCH * 64);
   };
 
+  if constexpr (IL) {
+    constexpr int NM = 2 * MT * NT;              // MFMAs of a tap
+    constexpr int NR = 2 * NT + 2 * MT;          // its regular fillers: weight loads (tap t + 3), pixel reads (tap t + 1)
+    constexpr int LT0 = 1, PT0 = 6;              // staging: slot s is requested at tap LT0 + s, parked at tap PT0 + s; barrier after tap 9
+    static_assert(LT0 + SL <= PT0 && PT0 + SL <= 10, "staging schedule");
+#ifndef WINO_WRING
+#define WINO_WRING 4
+#endif
+#ifndef WINO_ABL
+#define WINO_ABL 0
+#endif
+    constexpr int ABL = WINO_ABL;                // (compile-time ablation of the interleaved loop: 1 no weight loads, 2 no raw-row loads, 4 no MFMAs, 8 no pixel reads, 16 no park)
+    constexpr int WR = WINO_WRING, WA = WR - 1;  // weight fragments of WR taps: loaded WA taps ahead (WR divides 24)
+    static_assert(24 % WR == 0, "ring");
+    half8 wq[WR][NT][2];
+    half8 tq[4];                                 // the transformed pieces of the slot being parked
+    load_rows(0);
+#pragma unroll
+    for (int i = 0; i < WA; ++i) load_w(wq[i], i, 0);
+    // (first patch: every slot valid or dumped -- the plain park with the predicate replaced by the dump address)
+#pragma unroll
+    for (int j = 0; j < SL; ++j) {
+      const half8 d0 = __builtin_bit_cast(half8, raw[j][0]), d1 = __builtin_bit_cast(half8, raw[j][1]);
+      const half8 d2 = __builtin_bit_cast(half8, raw[j][2]), d3 = __builtin_bit_cast(half8, raw[j][3]);
+      unsigned char* d = smem + dst_off[j];
+      *reinterpret_cast<half8*>(d) = pk_sub(d0, d2);
+      *reinterpret_cast<half8*>(d + PITCH * 64) = d1 + d2;
+      *reinterpret_cast<half8*>(d + 2 * PITCH * 64) = pk_sub(d2, d1);
+      *reinterpret_cast<half8*>(d + 3 * PITCH * 64) = pk_sub(d1, d3);
+    }
+    WTS(1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    WTS(2);
+    read_b(bf[0], 0, 0, 0);
+    read_b(bf[1], 0, 1, 0);
+#pragma unroll 1
+    for (int pair = 0; pair < n_chunks; pair += 2) {
+#pragma unroll
+      for (int t = 0; t < 24; ++t) {
+        const int tt = t % 12, chunk_i = pair + t / 12, buf = t / 12;
+        const int f = tt / 3, kx = tt % 3;
+        const int chunk_n = chunk_i + 1 < n_chunks ? chunk_i + 1 : chunk_i;     // uniform; the last chunk re-stages itself
+        const int t3 = (tt + WA) % 12, c3 = tt + WA >= 12 ? chunk_n : chunk_i;
+        const int t1 = (tt + 2) % 12, buf1 = tt >= 10 ? buf ^ 1 : buf;        // (the pixel reads run two taps ahead)
+        const int soff3 = (t3 * c16 + c3 * 2) * 1024;
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+          const int ks = j / (MT * NT), mt = (j / NT) % MT, nt = j % NT;
+          if (!(ABL & 4)) acc[f][nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[t % WR][nt][ks], bf[t % 3][ks][mt], acc[f][nt][mt], 0, 0, 0);
+          else asm volatile("" :: "v"(wq[t % WR][nt][ks]), "v"(bf[t % 3][ks][mt]));
+#pragma unroll
+          for (int k = j * NR / NM; k < (j + 1) * NR / NM; ++k) {
+            if (k < 2 * NT) {
+              if (!(ABL & 1)) wq[(t + WA) % WR][k / 2][k % 2] =
+                  __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wfrag[k / 2] + (k % 2) * 1024, soff3, 0));
+            } else {
+              const int kk = k - 2 * NT, ks1 = kk / MT, mt1 = kk % MT;
+              if (!(ABL & 8)) bf[(t + 2) % 3][ks1][mt1] = *reinterpret_cast<const half8*>(smem + buf1 * PATCH_BYTES + rd_base[t1 % 3][ks1] + (mt1 * 8 + t1 / 3) * PITCH * 64);
+            }
+          }
+          if (tt >= LT0 && tt < LT0 + SL) {            // one slot's four raw rows: a load behind each of the first four MFMAs
+            const int sl = tt - LT0;
+            if (j < 4 && !(ABL & 2)) raw[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, row_off[j] + col_off[sl], (ABL & 32) ? 0 : chunk_n * BK * 2, 0);
+          }
+          if (tt >= PT0 && tt < PT0 + SL && !(ABL & 16)) {            // one slot parked: a transformed piece, then its store, per pair of MFMAs
+            const int sl = tt - PT0;
+            {                                            // 8 items over the tap's MFMAs
+#pragma unroll
+              for (int it = j * 8 / NM; it < (j + 1) * 8 / NM; ++it) {
+                const int fq = it >> 1;
+                if ((it & 1) == 0) {
+                  const half8 da = __builtin_bit_cast(half8, raw[sl][fq == 0 ? 0 : fq == 1 ? 1 : fq == 2 ? 2 : 1]);
+                  const half8 db = __builtin_bit_cast(half8, raw[sl][fq == 0 ? 2 : fq == 1 ? 2 : fq == 2 ? 1 : 3]);
+                  tq[fq] = fq == 1 ? da + db : pk_sub(da, db);
+                } else {
+                  *reinterpret_cast<half8*>(smem + (buf ^ 1) * PATCH_BYTES * (slot_ok[sl] ? 1 : 0) + dst_off[sl] + fq * PITCH * 64) = tq[fq];
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tt == 9) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    }
+    WTS(3);
+  } else {
   load_rows(0);
   load_w(wf[0], 0, 0);
   load_w(wf[1], 1, 0);
@@ -175,14 +300,17 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
       {
         const int t2 = (tt + 2) % 12;
         const int c2 = tt + 2 >= 12 ? (more ? chunk_i + 1 : chunk_i) : chunk_i;
-        load_w(wf[(t + 2) % 3], t2, c2);
+        if (!(dbg & 1)) load_w(wf[(t + 2) % 3], t2, c2);
       }
-      if (tt == PF_TAP && more) load_rows(chunk_i + 1);
+      if (tt == PF_TAP && more && !(dbg & 2)) load_rows(chunk_i + 1);
       // 2) the pixels of tap t + 1; across the chunk boundary from the other buffer (published by the barrier of tap 10)
-      if (tt != 11) read_b(bf[(t + 1) & 1], (tt + 1) / 3, (tt + 1) % 3, buf);
-      else if (more) read_b(bf[(t + 1) & 1], 0, 0, buf ^ 1);
+      if (!(dbg & 8)) {
+        if (tt != 11) read_b(bf[(t + 1) & 1], (tt + 1) / 3, (tt + 1) % 3, buf);
+        else if (more) read_b(bf[(t + 1) & 1], 0, 0, buf ^ 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
       // 3) this tap's MFMAs
+      if (!(dbg & 4))
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -193,16 +321,17 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
       __builtin_amdgcn_sched_barrier(0);
       // 4) the next chunk's patch: parked in the other buffer, published for tap 11's reads
       if (tt == 10 && more) {
-        park_rows(buf ^ 1);
+        if (!(dbg & 2)) park_rows(buf ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     }
   }
 
-  // ---- epilogue: y(2r) = M0 + M1 + M2, y(2r+1) = M1 - M2 - M3; bias last, ReLU on the rounded pairs, (2x2 max-pool), stores.
+  }     // !IL
+  if (dbg & 16) return;
+  // ---- epilogue: y(2r) = M0 + M1 + M2, y(2r+1) = M1 - M2 - M3 (the bias came in with M1), ReLU on the rounded pairs, (2x2 max-pool), stores.
   // acc register r of a tile holds channel (r & 3) + 8 (r >> 2) + 4 kgrp of pixel (pair-row frag_pr, column frag_px).
   constexpr int OOB = (int)0x80000000u;
-  const unsigned char* bias_lds = smem + BIAS_OFF;
   const int Ho = p.pool ? (p.H + 1) / 2 : p.H, Wo = p.pool ? (p.W + 1) / 2 : p.W;
   const unsigned img_elems = (unsigned)Ho * Wo * p.Cout;
   const __amdgpu_buffer_rsrc_t r16 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y16 + (size_t)b * img_elems), 0, img_elems * 2, 0x00020000);
@@ -228,14 +357,13 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
       unsigned pk[2][4][2];
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_lds + ((wn * NT + nt) * 32 + 8 * rq + 4 * kgrp) * 4);
         f32x4 e, o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = rq * 4 + j;
           const float m0 = acc[0][nt][mt][r], m1 = acc[1][nt][mt][r], m2 = acc[2][nt][mt][r], m3 = acc[3][nt][mt][r];
-          e[j] = ((m0 + m1) + m2) + bv[j];
-          o[j] = ((m1 - m2) - m3) + bv[j];
+          e[j] = (m0 + m1) + m2;
+          o[j] = (m1 - m2) - m3;
         }
         h2 e0 = {(half_t)e[0], (half_t)e[1]}, e1 = {(half_t)e[2], (half_t)e[3]};
         h2 o0 = {(half_t)o[0], (half_t)o[1]}, o1 = {(half_t)o[2], (half_t)o[3]};
@@ -260,7 +388,6 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
       // the lower half stores channels 16m..16m+7 and the upper half 16m+8..16m+15 -- 16-byte stores (conv.hip's epilogue)
 #pragma unroll
       for (int par = 0; par < 2; ++par) {
-        if (par == 1 && p.pool) break;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           auto sx = __builtin_amdgcn_permlane32_swap(pk[par][2 * m][0], pk[par][2 * m + 1][0], false, false);
@@ -271,15 +398,39 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles) {
       }
     }
   }
+  WTS(4);
+#ifdef WINO_TS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WTS(5);
+#endif
 }
 
-template <int TH, int BN, int WM, int WN>
+template <int TH, int BN, int WM, int WN, bool IL = false>
 int launch_wino_cfg(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = cdiv(a.W, TW), tiles_y = cdiv(a.H, TH), n_tiles = a.Cout / BN;
-  const size_t lds = 2 * (size_t)(TH / 2) * 4 * PITCH * 64 + BN * sizeof(float);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<TH, BN, WM, WN>),
+  const size_t lds = 2 * (size_t)(TH / 2) * 4 * PITCH * 64 + (IL ? 8192 : 0);
+  static const int dbg = tune_int("WCT_WINO_DBG", 0);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_kernel<TH, BN, WM, WN, IL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((conv3x3_wino_kernel<TH, BN, WM, WN>), dim3(tiles_x * tiles_y * n_tiles, a.B), dim3(256), lds, s, a, tiles_x, n_tiles);
+  hipLaunchKernelGGL((conv3x3_wino_kernel<TH, BN, WM, WN, IL>), dim3(tiles_x * tiles_y * n_tiles, a.B), dim3(256), lds, s, a, tiles_x, n_tiles, dbg);
+#ifdef WINO_TS
+  if (IL) {
+    (void)hipStreamSynchronize(s);
+    static unsigned long long host[8192 * 4 * 8];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(wino_ts), sizeof(host));
+    const int nb = (int)std::min<long>((long)tiles_x * tiles_y * n_tiles * a.B, 8192);
+    double sum[5] = {0}; unsigned long long t0 = ~0ull, t1 = 0;
+    for (int i = 0; i < nb * 4; ++i) {
+      const unsigned long long* h = host + (size_t)i * 8;
+      sum[0] += (double)(h[1] - h[0]); sum[1] += (double)(h[2] - h[1]); sum[2] += (double)(h[3] - h[2]);
+      sum[3] += (double)(h[4] - h[3]); sum[4] += (double)(h[5] - h[4]);
+      t0 = std::min(t0, h[0]); t1 = std::max(t1, h[5]);
+    }
+    fprintf(stderr, "WTS <%d,%d,%d,%d> Cin %d Cout %d H %d B %d blocks %d: prologue (entry -> first patch parked) %.0f, barrier %.0f, mainloop %.0f (%d chunks: %.0f per chunk), epilogue %.0f, store drain %.0f; first entry -> last exit %.0f cycles\n",
+            TH, BN, WM, WN, a.Cin, a.Cout, a.H, a.B, nb, sum[0] / (nb * 4), sum[1] / (nb * 4), sum[2] / (nb * 4), a.Cin / 32, sum[2] / (nb * 4) / (a.Cin / 32),
+            sum[3] / (nb * 4), sum[4] / (nb * 4), (double)(t1 - t0));
+  }
+#endif
   HIP_TRY(hipGetLastError());
   return WCT_OK;
 }
@@ -303,7 +454,14 @@ int launch_conv3x3_wino(const ConvArgs& a, hipStream_t s) {
   if (force == 1 && a.Cout % 128 == 0) return launch_wino_cfg<16, 128, 2, 2>(a, s);
   if (force == 2) return launch_wino_cfg<16, 64, 2, 2>(a, s);
   if (force == 3) return launch_wino_cfg<8, 64, 2, 2>(a, s);
-  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_wino_cfg<16, 128, 2, 2>(a, s);
-  if (px16 * (a.Cout / 64) >= 256) return launch_wino_cfg<16, 64, 2, 2>(a, s);
+  if (force == 4 && a.Cout % 128 == 0) return launch_wino_cfg<8, 128, 1, 4>(a, s);
+  if (force == 5 && a.Cout % 128 == 0) return launch_wino_cfg<16, 128, 1, 4>(a, s);
+  if (force == 6 && a.Cout % 128 == 0) return launch_wino_cfg<16, 128, 1, 4, true>(a, s);
+  if (force == 7 && a.Cout % 128 == 0) return launch_wino_cfg<16, 128, 2, 2, true>(a, s);
+  // one 256-pixel x 128-channel block per CU with the interleaved schedule where that fills the chip; below, blocks of 8 rows at
+  // two per CU (the second block covers the first one's prologue and epilogue)
+  const long px8 = (long)cdiv(a.W, TW) * cdiv(a.H, 8) * a.B;
+  if (a.Cout % 128 == 0 && px16 * (a.Cout / 128) >= 256) return launch_wino_cfg<16, 128, 1, 4, true>(a, s);
+  if (a.Cout % 128 == 0 && px8 * (a.Cout / 128) >= 256) return launch_wino_cfg<8, 128, 1, 4>(a, s);
   return launch_wino_cfg<8, 64, 2, 2>(a, s);
 }
