@@ -89,32 +89,37 @@ _WINO_G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], np.float
 _WINO_BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], np.float64)
 
 
-def conv3x3_reflect_wino_f16(x, w_hwio, b, relu=True):
+def wino_layer(cin, cout):
+    """The layers the MI355X path runs on its reduced-FLOP kernel (csrc/api.hip::wino_layer; tap layers excepted there)."""
+    return cin >= 256 and cout >= 256
+
+
+def conv3x3_reflect_wino_f16(x, w_hwio, b, relu=True, acc=np.float64):
     """The SAME layer as conv3x3_reflect with the roundings of the MI355X path's reduced-FLOP kernel (csrc/conv_wino.hip:
     Winograd F(2,3) along y, direct along x) -- not a reference mode, a restatement that shows accumulation order only:
     activations rounded to fp16; filters U_f[kx] = sum_ky G[f][ky] g[ky][kx] rounded to fp16; transformed rows T = B^T d
     computed from the fp16 activations and rounded to fp16 (one add per value); products exact, sums in float64;
     y(2r) = M0 + M1 + M2, y(2r+1) = M1 - M2 - M3; bias, ReLU; the result rounded to fp16 (the kernel stores fp16)."""
-    x = np.asarray(x, np.float16).astype(np.float64)
+    x = np.asarray(x, np.float16).astype(acc)
     h, w, cin = x.shape
     cout = w_hwio.shape[3]
     he = h + (h & 1)                                     # an odd last row: its partner row is computed and dropped
     xp = np.pad(x, ((1, 1), (1, 1), (0, 0)), mode='reflect')
     if he != h:
         xp = np.concatenate([xp, xp[-1:]], 0)            # (the kernel clamps the row index there; the row only feeds the dropped output)
-    U = np.einsum('fk,kxio->fxio', _WINO_G, np.asarray(w_hwio, np.float64)).astype(np.float32).astype(np.float16).astype(np.float64)
+    U = np.einsum('fk,kxio->fxio', _WINO_G, np.asarray(w_hwio, np.float64)).astype(np.float32).astype(np.float16).astype(acc)
     rows = [xp[i:i + he:2] for i in range(4)]            # padded row 2r + i of every pair-row r
-    y = np.empty((he, w, cout), np.float64)
+    y = np.empty((he, w, cout), acc)
     M = []
     for f in range(4):
-        T = sum(_WINO_BT[f, i] * rows[i] for i in range(4)).astype(np.float16).astype(np.float64)    # [he/2][w+2][cin]
+        T = sum(acc(_WINO_BT[f, i]) * rows[i] for i in range(4) if _WINO_BT[f, i] != 0).astype(np.float16).astype(acc)    # [he/2][w+2][cin]
         m = 0
         for kx in range(3):
             m = m + T[:, kx:kx + w, :].reshape(-1, cin) @ U[f, kx]
         M.append(m.reshape(he // 2, w, cout))
     y[0::2] = (M[0] + M[1]) + M[2]
     y[1::2] = (M[1] - M[2]) - M[3]
-    y = y[:h] + np.asarray(b, np.float64)
+    y = y[:h] + np.asarray(b, acc)
     if relu:
         y = np.maximum(y, 0)
     return y.astype(np.float16).astype(np.float32)
@@ -146,14 +151,16 @@ def _h16(a):
     return np.asarray(a, np.float16).astype(np.float32)
 
 
-def encode(img01, weights, targets, fp16_storage=False):
+def encode(img01, weights, targets, fp16_storage=False, wino=True):
     """Run the shared VGG on an HxWx3 image in [0,1]; return {relu: features}
     for every relu name in `targets` (model.py:60-75,135-139).
 
     fp16_storage=True restates the SAME graph with the storage precision of the MI355X path: 3x3
     filters (conv1_1 excepted: it runs on split fp16 pairs, 22 bits) and the activations handed
     from layer to layer are rounded to fp16, sums and the tapped feature maps stay fp32.  It is not
-    a reference mode; it lets the stack tests use a tolerance that shows accumulation order only."""
+    a reference mode; it lets the stack tests use a tolerance that shows accumulation order only.  wino (with fp16_storage): the
+    layers that path runs on its reduced-FLOP kernel (>= 256 channels in and out, not a tap layer) with THAT kernel's roundings
+    (conv3x3_reflect_wino_f16)."""
     enc = weights['encoder']
     want = set(targets)
     deepest = sorted(want)[-1]                       # model.py:60
@@ -165,7 +172,10 @@ def encode(img01, weights, targets, fp16_storage=False):
             w = enc[name][0]
             if fp16_storage and name != 'conv1_1':
                 w = _h16(w)
-            x = conv3x3_reflect(x, w, enc[name][1], relu=True)
+            if fp16_storage and wino and wino_layer(layer[2], layer[3]) and not name.endswith('_1'):
+                x = conv3x3_reflect_wino_f16(x, enc[name][0], enc[name][1], relu=True, acc=np.float32)
+            else:
+                x = conv3x3_reflect(x, w, enc[name][1], relu=True)
             relu = 'relu' + name[4:]
             if relu in want:
                 feats[relu] = x
@@ -178,7 +188,7 @@ def encode(img01, weights, targets, fp16_storage=False):
     return feats
 
 
-def decode(feat, weights, relu_target, fp16_storage=False):
+def decode(feat, weights, relu_target, fp16_storage=False, wino=True):
     """Mirror decoder for `relu_target` (model.py:245-304).  fp16_storage: see encode (the decoder's input, every
     filter and every hand-over between layers in fp16; the 3-channel image stays fp32)."""
     x = np.asarray(feat, np.float32)
@@ -190,7 +200,10 @@ def decode(feat, weights, relu_target, fp16_storage=False):
         if kind == 'C':
             w, b = params[i]
             i += 1
-            x = conv3x3_reflect(x, _h16(w) if fp16_storage else w, b, relu=relu)
+            if fp16_storage and wino and cout != 3 and wino_layer(cin, cout):
+                x = conv3x3_reflect_wino_f16(x, w, b, relu=relu, acc=np.float32)
+            else:
+                x = conv3x3_reflect(x, _h16(w) if fp16_storage else w, b, relu=relu)
             if fp16_storage and cout != 3:
                 x = _h16(x)
         else:

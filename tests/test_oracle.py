@@ -310,3 +310,24 @@ def test_refresh_model_tracked_rotated_matrix_is_the_error_recomputed_one_is_not
         assert r[(name, 'refreshed')] < 1e-5 < r['reference'], (name, r)
     assert r[('V 22-bit', 'tracked')] > 1e-3 and r[('V 22-bit tol 1e-6', 'tracked')] > 1e-3, r     # more sweeps do not help
     assert r[('V 22-bit', 'no completion')] > 1e-3, r                                             # nor does dropping the completion
+
+
+def test_winograd_restatement_is_the_same_convolution():
+    """oracle.conv3x3_reflect_wino_f16 (the roundings of csrc/conv_wino.hip) on operands for which every rounding is exact -- small
+    integers, even filter taps so that G g has no halves -- IS conv3x3_reflect, to the bit: the transform matrices, the pair-row
+    bookkeeping (odd heights included) and the output transform are right.  On real-valued operands it stays within the
+    per-layer gate of the fp32 convolution (1.5e-3; measured ~3.7e-4)."""
+    rng = np.random.default_rng(5)
+    for h, w in [(6, 5), (7, 9), (2, 2)]:
+        x = rng.integers(-4, 5, (h, w, 8)).astype(np.float32)
+        g = (2 * rng.integers(-3, 4, (3, 3, 8, 16))).astype(np.float32)
+        b = rng.integers(-2, 3, 16).astype(np.float32)
+        for relu in (True, False):
+            assert np.array_equal(oracle.conv3x3_reflect_wino_f16(x, g, b, relu), oracle.conv3x3_reflect(x, g, b, relu))
+            assert np.array_equal(oracle.conv3x3_reflect_wino_f16(x, g, b, relu, acc=np.float32), oracle.conv3x3_reflect(x, g, b, relu))
+    x = np.maximum(rng.standard_normal((12, 10, 64)), 0).astype(np.float32)
+    g = (rng.standard_normal((3, 3, 64, 32)) * np.sqrt(2.0 / (9 * 64))).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32) * 0.1
+    ref = oracle.conv3x3_reflect(np.float32(np.float16(x)), g, b)
+    e = np.linalg.norm(oracle.conv3x3_reflect_wino_f16(x, g, b) - ref) / np.linalg.norm(ref)
+    assert e < 1.5e-3, e

@@ -530,10 +530,13 @@ static int check_min_size(const char* what, int H, int W, int level) {
 
 
 static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16, float* y32,
-                    int B, int H, int W, int upsample, int relu, int pool = 0, float* usum = nullptr, unsigned* umax = nullptr) {
+                    int B, int H, int W, int upsample, int relu, int pool = 0, float* usum = nullptr, unsigned* umax = nullptr,
+                    bool tap_layer = false) {
   ConvArgs a;
   a.x = x; a.w = l.w; a.bias = l.b; a.y16 = y16; a.y32 = y32; a.usum = usum; a.umax = umax;
-  a.w_wino = c->no_wino ? nullptr : l.ww;
+  // a layer whose output CAN be tapped (conv2_1 .. conv5_1) stays on the direct kernel in every pass, tapped or not: the kernel
+  // of a layer must not depend on which levels the caller asked for (fused == chained, bit for bit)
+  a.w_wino = c->no_wino || tap_layer ? nullptr : l.ww;
   a.B = B; a.H = H; a.W = W; a.Cin = l.cin; a.Cout = l.cout; a.upsample = upsample; a.relu = relu; a.pool = pool;
   const double px = (double)B * H * W;
   const double in_px = upsample ? px / 4 : px;
@@ -592,7 +595,7 @@ static int run_encoder(wct_ctx* c, const float* img, int B, int H, int W, int cl
       ProfScope ps(c, 8, 2.0 * px * (27 * 64 + 9 * 64 * 64), px * 12 + out_px * 64 * 2 + 9.0 * 64 * 64 * 2);
       TRY(launch_conv3x3(a, c->stream));
     } else
-    TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1, fuse, us, us ? umax[tap] : nullptr));
+    TRY(run_conv(c, l, cur, last ? nullptr : nxt, tap ? taps32[tap] : nullptr, B, h, w, 0, 1, fuse, us, us ? umax[tap] : nullptr, tap != 0));
     half_t* t = cur; cur = nxt; nxt = t;
     if (last) break;
     if (pool_after[i]) {

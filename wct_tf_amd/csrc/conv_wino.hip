@@ -198,7 +198,11 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles, int dbg_arg) {
   if constexpr (IL) {
     constexpr int NM = 2 * MT * NT;              // MFMAs of a tap
     constexpr int NR = 2 * NT + 2 * MT;          // its regular fillers: weight loads (tap t + 3), pixel reads (tap t + 1)
-    constexpr int LT0 = 1, PT0 = 6;              // staging: slot s is requested at tap LT0 + s, parked at tap PT0 + s; barrier after tap 9
+#ifndef WINO_LT0
+#define WINO_LT0 1
+#define WINO_PT0 6
+#endif
+    constexpr int LT0 = WINO_LT0, PT0 = WINO_PT0;              // staging: slot s is requested at tap LT0 + s, parked at tap PT0 + s; barrier after tap 9
     static_assert(LT0 + SL <= PT0 && PT0 + SL <= 10, "staging schedule");
 #ifndef WINO_WRING
 #define WINO_WRING 4
@@ -206,7 +210,10 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles, int dbg_arg) {
 #ifndef WINO_ABL
 #define WINO_ABL 0
 #endif
-    constexpr int ABL = WINO_ABL;                // (compile-time ablation of the interleaved loop: 1 no weight loads, 2 no raw-row loads, 4 no MFMAs, 8 no pixel reads, 16 no park)
+#ifndef WINO_RAW_AUX
+#define WINO_RAW_AUX 0         // cache policy of the raw-row loads (experiment: 1 sc0, 2 nt, 16 sc1)
+#endif
+    constexpr int ABL = WINO_ABL;                // (compile-time ablation of the interleaved loop: 1 no weight loads, 2 no raw-row loads, 4 no MFMAs, 8 no pixel reads, 16 no park, 32 raw rows of chunk 0 always, 64 raw-row loads of one cache line per instruction)
     constexpr int WR = WINO_WRING, WA = WR - 1;  // weight fragments of WR taps: loaded WA taps ahead (WR divides 24)
     static_assert(24 % WR == 0, "ring");
     half8 wq[WR][NT][2];
@@ -257,7 +264,7 @@ void conv3x3_wino_kernel(ConvArgs p, int tiles_x, int n_tiles, int dbg_arg) {
           }
           if (tt >= LT0 && tt < LT0 + SL) {            // one slot's four raw rows: a load behind each of the first four MFMAs
             const int sl = tt - LT0;
-            if (j < 4 && !(ABL & 2)) raw[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, row_off[j] + col_off[sl], (ABL & 32) ? 0 : chunk_n * BK * 2, 0);
+            if (j < 4 && !(ABL & 2)) raw[sl][j] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (ABL & 64) ? (lane & 3) * 16 + j * 64 + sl * 256 : row_off[j] + col_off[sl], (ABL & 32) ? 0 : chunk_n * BK * 2, WINO_RAW_AUX);
           }
           if (tt >= PT0 && tt < PT0 + SL && !(ABL & 16)) {            // one slot parked: a transformed piece, then its store, per pair of MFMAs
             const int sl = tt - PT0;
