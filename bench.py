@@ -472,8 +472,9 @@ def main():
                                 'workload (%s)' % traffic_src if traffic else 'no committed PMC pass for this batch/size',
                 'algorithmic_bytes_per_launch': conv['bytes'] / max(1, conv['launches']),
                 'kernel': 'conv3x3_mfma_kernel, the generic instantiations <..., false> (all their launches: the largest time class of '
-                          'the step, 61 per frame set; the tap launches -- 8 of them -- also take the transform\'s per-channel sums and '
-                          'maxima in their epilogue).  Up to round 3 / profiles/r04_final the class had 65 launches: the four 64->64 '
+                          'the step; since round 6 the >= 256-channel layers without a tap run on conv3x3_wino_kernel -- field conv_wino, '
+                          'and conv3x3_direct_and_wino for the 61 launches per frame set that were this class up to round 5; the tap '
+                          'launches -- 8 of them -- also take the transform\'s per-channel sums and maxima in their epilogue).  Up to round 3 / profiles/r04_final the class had 65 launches: the four 64->64 '
                           '@512^2 pooled conv1_2 launches of the content passes (0.25 of peak) now run as the instantiation '
                           '<32,64,4,1,true> with conv1_1 inside the patch loader -- class conv12, next field -- and '
                           'all_conv3x3_instantiations gives the figure over both for comparison with the earlier rounds',
@@ -481,6 +482,21 @@ def main():
                 'algorithmic_flops_per_frame': conv_flops_per_frame(S),
                 'algorithmic_gbytes_per_s': conv['bytes'] / (conv['ms'] * 1e-3) / 1e9 if conv['ms'] > 0 else 0.0,
             }
+            cw = prof.get('conv_wino')
+            if cw and cw['ms'] > 0:
+                aw = cw['flops'] / (cw['ms'] * 1e-3) / 1e12
+                line['roofline']['conv_wino'] = {
+                    'kernel': 'conv3x3_wino_kernel (csrc/conv_wino.hip): the >= 256-channel 3x3 layers without a feature tap on Winograd F(2,3) '
+                              'along y x direct along x -- 12 MFMA products per 2 outputs instead of 18.  achieved / frac are quoted on the '
+                              'DIRECT convolution\'s FLOPs (comparable with the class above); executed = the MFMA FLOPs the kernel issues (2/3)',
+                    'achieved': aw, 'frac': aw / MFMA_F16_DENSE_PEAK_TFLOPS,
+                    'executed_tflops': aw / 1.5, 'executed_frac': aw / 1.5 / MFMA_F16_DENSE_PEAK_TFLOPS,
+                    'launches': cw['launches'], 'avg_launch_ms': cw['ms'] / max(1, cw['launches'])}
+                allc = (conv['flops'] + cw['flops']) / ((conv['ms'] + cw['ms']) * 1e-3) / 1e12
+                line['roofline']['conv3x3_direct_and_wino'] = {
+                    'achieved': allc, 'frac': allc / MFMA_F16_DENSE_PEAK_TFLOPS, 'launches': conv['launches'] + cw['launches'],
+                    'ms_per_step': (conv['ms'] + cw['ms']) / args.steps,
+                    'note': 'the 61 launches per frame set that were ONE class up to round 5 (direct-convolution FLOPs / time): compare with roofline.frac of the earlier rounds'}
             c12 = prof.get('conv12')
             if c12 and c12['ms'] > 0:
                 a12 = c12['flops'] / (c12['ms'] * 1e-3) / 1e12

@@ -30,7 +30,8 @@ for cin, cout, h, up, pool, cnt in SHAPES:
         for _ in range(5):
             ctx.conv3x3_f16(x, w, b, True, bool(up), bool(pool), algo)
         ctx.prof_enable(False)
-        ms.append(ctx.prof_read()['conv3x3']['ms'] / 5)
+        pr = ctx.prof_read()
+        ms.append((pr['conv3x3']['ms'] + pr['conv_wino']['ms']) / 5)
     fl = 2.0 * h * batch * h * 9 * cin * cout
     tot[0] += ms[0] * cnt; tot[1] += ms[1] * cnt
     print('%3d->%3d @%3d up=%d pool=%d x%d: direct %.3f ms %5.0f TFLOP/s | winograd %.3f ms %5.0f TFLOP/s of the direct FLOPs (%4.0f executed) | x%.2f'

@@ -16,7 +16,8 @@ ctx.prof_reset(); ctx.prof_enable(True)
 for _ in range(5):
     ctx.conv3x3_f16(x, w, b, True, bool(up), bool(pool), algo)
 ctx.prof_enable(False)
-ms = ctx.prof_read()['conv3x3']['ms'] / 5
+pr = ctx.prof_read()
+ms = (pr['conv3x3']['ms'] + pr['conv_wino']['ms']) / 5
 fl = 2.0 * h * batch * h * 9 * cin * cout
 print('%3d->%3d @%3d up=%d pool=%d batch %d algo %d CFG=%s DBG=%s: %.3f ms  %5.0f TFLOP/s (direct FLOPs)' % (
     cin, cout, h, up, pool, batch, algo, os.environ.get('WCT_WINO_CFG', '-'), os.environ.get('WCT_WINO_DBG', '-'), ms, fl / ms / 1e9))

@@ -541,7 +541,8 @@ static int run_conv(wct_ctx* c, const ConvLayer& l, const half_t* x, half_t* y16
   const double px = (double)B * H * W;
   const double in_px = upsample ? px / 4 : px;
   const double out_px = pool ? (double)B * ((H + 1) / 2) * ((W + 1) / 2) : px;
-  ProfScope ps(c, 0, 2.0 * px * 9 * l.cin * l.cout,
+  // class 9: the launches the reduced-FLOP kernel takes; flops = the DIRECT convolution's (the kernel executes 2/3 of them)
+  ProfScope ps(c, conv3x3_wino_takes(a) ? 9 : 0, 2.0 * px * 9 * l.cin * l.cout,
                in_px * l.cin * 2 + out_px * l.cout * ((y16 ? 2 : 0) + (y32 ? 4 : 0)) + 9.0 * l.cin * l.cout * 2);
   return launch_conv3x3(a, c->stream);
 }

@@ -17,6 +17,13 @@
 #include <utility>
 #include <vector>
 
+// A launcher that returns void (the per-launch helpers of the eigensolver's trains) notes a refused launch here, with the kernel's
+// name, the moment it happens; the train's driver returns it (launch_rc_take) instead of a generic failure at a later sync.
+static thread_local int launch_rc_sticky = WCT_OK;
+#define LAUNCH_NOTE(what) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess && launch_rc_sticky == WCT_OK) { \
+    wct_set_error("launch of %s refused: %s (%s:%d)", what, hipGetErrorString(e_), __FILE__, __LINE__); launch_rc_sticky = WCT_ERR_HIP; } } while (0)
+static inline int launch_rc_take() { const int r = launch_rc_sticky; launch_rc_sticky = WCT_OK; return r; }
+
 // ---------------------------------------------------------------------------
 // K3: per-channel sums over the pixel axis
 // ---------------------------------------------------------------------------
@@ -1591,8 +1598,10 @@ static void jacobi_fused_launch(JacobiGroup& G, int C, int seg_begin, bool has_d
     else
 #endif
     hipLaunchKernelGGL((jacobi_fused4_kernel<M2, 0>), dim3(grid), dim3(r4::Lay<0>::NTD), (r4::fused_lds<M2, 0>(has_d, has_u, first, step_d)), G.stream, a);
+    LAUNCH_NOTE("jacobi_fused4_kernel");
   } else {
     hipLaunchKernelGGL((jacobi_fused_kernel<M2>), dim3(grid), dim3(NT), jacobi_fused_lds<M2>(has_d, has_u, first, step_d), G.stream, a);
+    LAUNCH_NOTE("jacobi_fused_kernel");
   }
 #ifdef JACOBI_TS
   static const int ts_intra = getenv("WCT_TS_INTRA") != nullptr;      // (-DJACOBI_TS builds only) summarise the intra steps instead
@@ -1666,14 +1675,12 @@ static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_
   a.mat_major = xcd && G.nmat % 8 == 0;
 #define VSTRIP_CASE(m2, nb, w) \
   if (M2 == m2 && nblk == nb) {                                                                                      \
-    static bool raised[16] = {};                                                                                     \
-    int dev = 0;                                                                                                     \
     const size_t vs_lds = (vstrip_lds_bytes<m2, w>());                                                               \
-    if (vs_lds > 64 * 1024 && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16 && !raised[dev]) {            \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_vstrip_kernel<m2, nb, w>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds); \
-      raised[dev] = true;                                                                                            \
-    }                                                                                                                \
+    /* (every launch: cheap, idempotent, no per-device flag to race on -- ADVICE r5; a refusal is reported here) */   \
+    if (vs_lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi_vstrip_kernel<m2, nb, w>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vs_lds) != hipSuccess) \
+      LAUNCH_NOTE("jacobi_vstrip_kernel (hipFuncSetAttribute: dynamic LDS above 64 KiB)");                            \
     hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), a.mat_major ? dim3(G.nmat, C / 16 / w) : dim3(C / 16 / w, G.nmat), dim3(w * 64), vs_lds, s, a); \
+    LAUNCH_NOTE("jacobi_vstrip_kernel");                                                                             \
   }
   VSTRIP_CASE(64, 16, 4) VSTRIP_CASE(64, 8, 8) VSTRIP_CASE(32, 8, 4) VSTRIP_CASE(32, 4, 4) VSTRIP_CASE(32, 2, 2)
 #undef VSTRIP_CASE
@@ -1721,6 +1728,7 @@ static void jacobi_measure(JacobiGroup& G, int C, const JacobiCheckArgs& ck) {
   const int ntile = ntr * (ntr + 1) / 2;
   hipLaunchKernelGGL(jacobi_resid_kernel, dim3(ntile, G.nmat), dim3(256), 0, G.stream, G.P[G.cur], G.st, G.resid, C);
   hipLaunchKernelGGL(jacobi_check_kernel, dim3(G.nmat), dim3(64), 0, G.stream, G.st, G.resid, ntile, G.tol_fn > 2e-2f ? 7.1f : 1.f, ck);
+  LAUNCH_NOTE("jacobi_resid_kernel / jacobi_check_kernel");
 }
 
 template <int M2>
@@ -1742,6 +1750,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     G.vstrip = host && g < 4 && vstrip_supported<M2>(C) && (vs_env == 2 || (vs_env == 1 && G.nmat >= vs_min && C >= 256));
     if (G.vstrip) { G.vs = host->vs[g]; G.ev_seg = host->ev_seg[g]; G.ev_v[0] = host->ev_v[g][0]; G.ev_v[1] = host->ev_v[g][1]; }
     hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, G.nmat), dim3(256), 0, G.stream, G.A, G.V, G.st, C, G.mat0, G.shared_style);
+    HIP_TRY(hipGetLastError());
   }
   bool pending = false;
   int rc;
@@ -1790,11 +1799,13 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     for (int l = 0; l < 2; ++l)            // the V passes still in flight belong to this solve
       if (G.vstrip && G.v_busy[l]) { HIP_TRY(hipStreamWaitEvent(G.stream, G.ev_v[l], 0)); G.v_busy[l] = false; }
     hipLaunchKernelGGL(jacobi_gather_kernel, dim3(32, G.nmat), dim3(256), 0, G.stream, G.A, G.P[1], G.st, C, G.cur);
+    HIP_TRY(hipGetLastError());
     if (G.sweeps_out || G.fail || G.stats)
       hipLaunchKernelGGL(jacobi_finalize_kernel, dim3(1), dim3(64), 0, G.stream, G.st, G.sweeps_out, G.nmat, conv_tol, G.tol_fn, G.fail, tune_set("WCT_JACOBI_DEBUG"), G.stats);
+      HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipGetLastError());
-  return WCT_OK;
+  return launch_rc_take();           // a launch one of the train's void helpers saw refused (named there)
 }
 
 static int jacobi_make_group(JacobiGroup* G, float* A, float* V, int C, int nmat, void* workspace, size_t workspace_bytes,
@@ -2165,9 +2176,11 @@ static int launch_spectral_function(const float* A, const float* V, float* G, fl
   const size_t cc = (size_t)C * C;
   const dim3 tiles(cdiv(C, 64), cdiv(C, 64), nbatch);
   hipLaunchKernelGGL(spectral_matrix_kernel, tiles, dim3(256), 0, s, A, G, C, stride, kind, shift, eig_correct_enabled());
+  HIP_TRY(hipGetLastError());
   if (scratch2 && eig_correct_enabled() >= 2) {
     float* N = scratch2; float* R = N + nbatch * cc; float* Pm = R + nbatch * cc; float* X1 = Pm + nbatch * cc; float* X2 = X1 + nbatch * cc;
     hipLaunchKernelGGL(spectral_prep2_kernel, tiles, dim3(256), 0, s, A, N, R, Pm, C, stride, kind, shift);
+    HIP_TRY(hipGetLastError());
     GemmArgs a = {};   // X2 = (kind 1: N, kind 0: P) N
     a.A = kind == 1 ? N : Pm; a.lda = C; a.a_kmajor = 0; a.B = N; a.ldb = C; a.b_kmajor = 1; a.sA = a.sB = cc;
     a.M = C; a.N = C; a.K = C; a.ksplit = C; a.out32 = X2; a.ldo = C; a.s_out = cc;
@@ -2178,6 +2191,7 @@ static int launch_spectral_function(const float* A, const float* V, float* G, fl
       if ((rc2 = launch_gemm(a, 1, nbatch, s))) return rc2;
     }
     hipLaunchKernelGGL(spectral_add2_kernel, tiles, dim3(256), 0, s, A, G, X1, X2, C, stride, kind, shift);
+    HIP_TRY(hipGetLastError());
   }
   GemmArgs g = {};   // X = V G
   g.A = V; g.lda = C; g.a_kmajor = 0; g.B = G; g.ldb = C; g.b_kmajor = 1; g.sA = g.sB = stride;
@@ -2461,6 +2475,24 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
   return WCT_OK;
 }
 
+// refresh (see refresh_needed): X = A0 V, then A <- V^T X, for the matrices whose kept spectrum reaches 4 decades below their
+// norm; the others' blocks exit at once.  Before ANY spectral function of the tracked (A, V): launch_wct's apply stage and the
+// three of launch_style_swap (relu5_1, C = 512: every input of 352 x 352 or smaller has N < C -- the rank-deficient case).
+static int launch_refresh(const WctCarve& w, int C, int P, int shared_style, hipStream_t s) {
+  const size_t cc = (size_t)C * C;
+  int rc;
+  GemmArgs r1 = {};
+  r1.A = w.A0; r1.lda = C; r1.a_kmajor = 0; r1.B = w.V; r1.ldb = C; r1.b_kmajor = 1; r1.sA = r1.sB = cc; r1.skip_shared = shared_style;
+  r1.M = C; r1.N = C; r1.K = C; r1.ksplit = C; r1.out32 = w.X; r1.ldo = C; r1.s_out = cc;
+  r1.mask_diag = w.A; r1.s_mask = cc; r1.mask_out = w.refresh;
+  if ((rc = launch_gemm(r1, 1, 2 * P, s))) return rc;
+  GemmArgs r2 = {};
+  r2.A = w.V; r2.lda = C; r2.a_kmajor = 1; r2.B = w.X; r2.ldb = C; r2.b_kmajor = 1; r2.sA = r2.sB = cc; r2.skip_shared = shared_style;
+  r2.M = C; r2.N = C; r2.K = C; r2.ksplit = C; r2.out32 = w.A; r2.ldo = C; r2.s_out = cc;
+  r2.mask_in = w.refresh;
+  return launch_gemm(r2, 1, 2 * P, s);
+}
+
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
                half_t* out16, float* out32, void* workspace, size_t workspace_bytes, int* sweeps_dev,
                int stages, hipStream_t s, const hipStream_t* side, int nside, hipEvent_t ev_fork,
@@ -2486,6 +2518,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
     dim3 grid(ca.ntile * (ca.ntile + 1) / 2, w.nsplit, 2 * P);
     if (BT == 128) hipLaunchKernelGGL((cov_f16x2_kernel<128>), grid, dim3(256), 0, s, ca);
     else hipLaunchKernelGGL((cov_f16x2_kernel<64>), grid, dim3(256), 0, s, ca);
+    HIP_TRY(hipGetLastError());
   }
   // eps_in < 0 selects the reference defaults: 1e-8 on the covariance diagonal for wct_tf
   // (ops.py:24,45,50), 1e-5 inside the spectral gains for wct_np (ops.py:92,114,127)
@@ -2493,6 +2526,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
   const float eps = mode == WCT_MODE_TF ? eps_user : 0.f;
   hipLaunchKernelGGL(cov_finish_kernel, dim3(cdiv(C, 64), cdiv(C, 64), 2 * P), dim3(256), 0, s,
                      w.cov_partial, w.scale, w.A, C, w.nsplit, BT, 1.f / (float)(Nc - 1), 1.f / (float)(Ns - 1), eps, shared_style, w.A0);
+  HIP_TRY(hipGetLastError());
   }
   if (stages & WCT_STAGE_EIG) {
     if (nside > 0 && P >= 2) {
@@ -2545,26 +2579,14 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
     const float shift = mode == WCT_MODE_NP ? (eps_in >= 0.f ? eps_in : 1e-5f) : 0.f;
     const int second = eig_correct_enabled() >= 2;
     const dim3 tiles(cdiv(C, 64), cdiv(C, 64), 2 * P);
-    {
-      // refresh (see refresh_needed): X = A0 V, then A <- V^T X, for the matrices whose kept spectrum reaches 4 decades below
-      // their norm; the others' blocks exit at once
-      GemmArgs r1 = {};
-      r1.A = w.A0; r1.lda = C; r1.a_kmajor = 0; r1.B = w.V; r1.ldb = C; r1.b_kmajor = 1; r1.sA = r1.sB = cc; r1.skip_shared = shared_style;
-      r1.M = C; r1.N = C; r1.K = C; r1.ksplit = C; r1.out32 = w.X; r1.ldo = C; r1.s_out = cc;
-      r1.mask_diag = w.A; r1.s_mask = cc; r1.mask_out = w.refresh;
-      if ((rc = launch_gemm(r1, 1, 2 * P, s))) return rc;
-      GemmArgs r2 = {};
-      r2.A = w.V; r2.lda = C; r2.a_kmajor = 1; r2.B = w.X; r2.ldb = C; r2.b_kmajor = 1; r2.sA = r2.sB = cc; r2.skip_shared = shared_style;
-      r2.M = C; r2.N = C; r2.K = C; r2.ksplit = C; r2.out32 = w.A; r2.ldo = C; r2.s_out = cc;
-      r2.mask_in = w.refresh;
-      if ((rc = launch_gemm(r2, 1, 2 * P, s))) return rc;
-    }
+    if ((rc = launch_refresh(w, C, P, shared_style, s))) return rc;
     SpecAllArgs sa = {};
     sa.A = w.A; sa.G = w.G; sa.C = C; sa.shift = shift; sa.correct = eig_correct_enabled(); sa.second = second; sa.shared_style = shared_style;
     sa.N = w.S2; float* X2 = sa.N + 2 * P * cc; sa.R = X2 + 2 * P * cc; sa.Pm = sa.R + P * cc; float* X1 = sa.Pm + P * cc;
     sa.X1 = X1; sa.X2 = X2;
     sa.mabs = w.mabs; sa.mean = w.mean; sa.bias = w.bias; sa.alpha = alpha; sa.mode = mode;
     hipLaunchKernelGGL(spectral_open_all_kernel, tiles, dim3(256), 0, s, sa);
+    HIP_TRY(hipGetLastError());
     if (second) {
       GemmArgs a = {};   // X2[m] = (colouring: N[m], whitening: Pm[pair]) . N[m]
       a.A = sa.Pm; a.sA = cc; a.A_odd = sa.N + cc; a.sA_odd = 2 * cc; a.lda = C; a.a_kmajor = 0;
@@ -2576,6 +2598,7 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
       b.M = C; b.N = C; b.K = C; b.ksplit = C; b.out32 = X1; b.ldo = C; b.s_out = cc;
       if ((rc = launch_gemm(b, 1, P, s))) return rc;
       hipLaunchKernelGGL(spectral_add2_all_kernel, tiles, dim3(256), 0, s, sa);
+      HIP_TRY(hipGetLastError());
     }
     GemmArgs g = {};   // X[m] = V[m] G[m]
     g.A = w.V; g.lda = C; g.a_kmajor = 0; g.B = w.G; g.ldb = C; g.b_kmajor = 1; g.sA = g.sB = cc; g.skip_shared = shared_style;
@@ -2813,6 +2836,7 @@ int launch_style_swap(const float* content, int hc, int wc, const float* style, 
   const size_t cc = (size_t)C * C;
   // content whitening, style whitening, style colouring: S^-1/2 | S^1/2 over the kept singular values, no eps in the
   // gains (ops.py:187-189,197-198,208-209), with the first-order completion on the solver's residual
+  if ((rc = launch_refresh(w, C, 1, 0, s))) return rc;
   if ((rc = launch_spectral_function(w.A, w.V, w.G, w.X, w.Tw, C, 1, 2 * cc, cc, 0, 0.f, s, w.S2))) return rc;
   if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.Tcs, C, 1, 2 * cc, cc, 0, 0.f, s, w.S2))) return rc;
   if ((rc = launch_spectral_function(w.A + cc, w.V + cc, w.G + cc, w.X + cc, w.T, C, 1, 2 * cc, cc, 1, 0.f, s, w.S2))) return rc;
@@ -2827,6 +2851,7 @@ int launch_style_swap(const float* content, int hc, int wc, const float* style, 
   hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid((size_t)Mo * K / 4)), dim3(256), 0, s, sw.Wc, sw.Ac, wc, C, patch, stride, ho, wo);
   hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid((size_t)Pn * K / 4)), dim3(256), 0, s, sw.Ws, sw.Bs, ws, C, patch, stride, rows, cols);
   hipLaunchKernelGGL(patch_axis_inv_norm_kernel, dim3(cdiv(K / 4, 64)), dim3(64), 0, s, sw.Bs, sw.inv, Pn, K);
+  HIP_TRY(hipGetLastError());
   {  // E[m][n] = sum_k Ac[m][k] inv[k] Bs[n][k]
     GemmArgs g = {};
     g.A = sw.Ac; g.lda = K; g.a_kmajor = 0; g.a_scale_k = sw.inv; g.B = sw.Bs; g.ldb = K; g.b_kmajor = 0;
@@ -2834,8 +2859,10 @@ int launch_style_swap(const float* content, int hc, int wc, const float* style, 
     if ((rc = launch_gemm(g, 1, 1, s))) return rc;
   }
   hipLaunchKernelGGL(row_argmax_kernel, dim3(Mo), dim3(64), 0, s, sw.E, sw.idx, Pn);
+  HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(swap_reconstruct_kernel, dim3(ew_grid((size_t)Nc * C / 4)), dim3(256), 0, s, sw.Bs, sw.idx, sw.ss,
                      hc, wc, C, patch, stride, ho, wo);
+  HIP_TRY(hipGetLastError());
   {  // col = ss . Tcol^T
     GemmArgs g = {};
     g.A = sw.ss; g.lda = C; g.a_kmajor = 0; g.B = w.T; g.ldb = C; g.b_kmajor = 0;
