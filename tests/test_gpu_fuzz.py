@@ -8,6 +8,8 @@ What the sweep is after:
   * AdaIN: same shapes;
   * conv3x3: any H, W >= 2, channel counts from the path, with and without the folded upsample / ReLU;
   * CORAL: arbitrary image sizes (exact integer moments)."""
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -32,6 +34,24 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+@contextlib.contextmanager
+def _memoised_svd():
+    """np.linalg.svd with its results cached by the argument's bytes (test infrastructure: the oracle's keep= sweeps decompose the
+    same two covariances at every candidate)."""
+    real, cache = np.linalg.svd, {}
+
+    def svd(a, *args, **kw):
+        key = (a.shape, a.dtype.str, hash(a.tobytes()), args, tuple(sorted(kw.items())))
+        if key not in cache:
+            cache[key] = real(a, *args, **kw)
+        return cache[key]
+    np.linalg.svd = svd
+    try:
+        yield
+    finally:
+        np.linalg.svd = real
 
 
 def features(rng, n, c, scale, mix=True):
@@ -76,10 +96,11 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
         cand = [sorted({r[0], min(r[0] + 1, r[1]), max(r[1] - 1, r[0]), r[1]}) for r in ranges]
     wide = max(r[1] - r[0] for r in ranges) >= 8
     errs = {}
-    for kc in cand[0]:
-        for ks in cand[1]:
-            # (wide bands are judged against the float64 outcomes below: the float32 ones are not evaluated -- two SVDs apiece)
-            errs[(kc, ks)] = float('nan') if wide else rel_err(got, np.asarray(fn(*shaped, alpha, keep=(kc, ks))).reshape(nc, c))
+    with _memoised_svd():                # (the float32 candidates decompose the same two covariances: once)
+        for kc in cand[0]:
+            for ks in cand[1]:
+                # (wide bands are judged against the float64 outcomes below: the float32 ones are not evaluated)
+                errs[(kc, ks)] = float('nan') if wide else rel_err(got, np.asarray(fn(*shaped, alpha, keep=(kc, ks))).reshape(nc, c))
     # A WIDE band is a whole cluster of rounding-noise eigenvalues sitting on the cut-off (N < C pixels at a feature
     # scale whose noise is ~1e-5 or above): every noise direction the reference happens to keep is amplified by up to
     # (1e-5)^-1/2 = 316, and its own output is then rounding noise at the 1e-3..1e-2 level -- measured here as the
@@ -112,9 +133,23 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     STATS['wct_wide'] += 1
     sh64 = (np.float64(shaped[0]), np.float64(shaped[1]))
     kw64 = {'dtype': np.float64} if mode == 'tf' else {}
-    exact = {k: np.asarray(fn(*sh64, alpha, keep=k, **kw64)).reshape(nc, c) for k in errs}
+    # Round 6: the ends of a very wide band are not where this path's OWN kept count lies -- the 7-8e-4 cases of round 5
+    # were judged at the wrong outcome.  The exact outcome is now searched over the WHOLE band by coordinate descent from the best
+    # end candidate (content count with the style count fixed, then the style count, twice); the two float64 SVDs are computed once
+    # (np.linalg.svd memoised for the duration: the oracle stays as it is), so a candidate costs a few small products.
+    exact = {}
+    with _memoised_svd():
+        def ex(k):
+            if k not in exact:
+                exact[k] = np.asarray(fn(*sh64, alpha, keep=k, **kw64)).reshape(nc, c)
+            return exact[k]
+        best = min(errs, key=lambda k: rel_err(got, ex(k)))
+        for _ in range(2):
+            best = min(((kc, best[1]) for kc in range(ranges[0][0], ranges[0][1] + 1)), key=lambda k: rel_err(got, ex(k)))
+            best = min(((best[0], ks) for ks in range(ranges[1][0], ranges[1][1] + 1)), key=lambda k: rel_err(got, ex(k)))
     gpu_exact = min(rel_err(got, e) for e in exact.values())
     ref_noise = min(rel_err(o32, e) for e in exact.values())
+    print('   wide band: %d exact outcomes visited, this path nearest to kept counts %s' % (len(exact), best))
     STATS['wct_wide_worst'] = max(STATS['wct_wide_worst'], gpu_exact)
     print('   wide band: vs the exact (float64) outcomes of the band: this path %.2e, the reference in float32 %.2e'
           % (gpu_exact, ref_noise))

@@ -507,6 +507,8 @@ def test_coral_matches_reference(ctx):
     (512, 32, 32, 32, 32, 3, 1),       # relu5_1 of a 512x512 pair
     (128, 9, 11, 8, 8, 1, 1),
     (64, 11, 13, 9, 9, 3, 2),          # stride 2 on sizes that survive the round trip
+    (512, 16, 16, 16, 16, 3, 1),       # N = 256 < C: rank-deficient covariances on both sides (relu5_1 of a 256x256 pair) -- the
+    (512, 22, 22, 12, 20, 3, 1),       # case the refresh A <- V^T A0 V exists for (it was wired into launch_wct only)
 ])
 def test_style_swap(ctx, c, hc, wc, hs, ws, p, st):
     from wct_tf_amd import ops
