@@ -1682,7 +1682,7 @@ static void vstrip_launch(const JacobiGroup& G, int C, int step_begin, int step_
     hipLaunchKernelGGL((jacobi_vstrip_kernel<m2, nb, w>), a.mat_major ? dim3(G.nmat, C / 16 / w) : dim3(C / 16 / w, G.nmat), dim3(w * 64), vs_lds, s, a); \
     LAUNCH_NOTE("jacobi_vstrip_kernel");                                                                             \
   }
-  VSTRIP_CASE(64, 16, 4) VSTRIP_CASE(64, 8, 8) VSTRIP_CASE(32, 8, 4) VSTRIP_CASE(32, 4, 4) VSTRIP_CASE(32, 2, 2)
+  VSTRIP_CASE(64, 16, 4) VSTRIP_CASE(64, 8, 4) VSTRIP_CASE(32, 8, 4) VSTRIP_CASE(32, 4, 4) VSTRIP_CASE(32, 2, 2)
 #undef VSTRIP_CASE
 }
 
