@@ -1096,6 +1096,112 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
       *reinterpret_cast<f32x4*>(Vm + (size_t)(g * M2 + 16 * ti + li) * C + pair_index<B>(16 * tj + 4 * lq, hi, hj)) = acc[tj];
     return;
   }
+#ifndef WCT_JACOBI_U_F32
+  // Round 6: the update of an off-diagonal tile, Y = Q_g^T (X Q_h), on the fp16 MFMA pipe with split operands (the V task's scheme)
+  // instead of 2 x 64 v_mfma_f32_16x16x4_f32 per wave -- 48 v_mfma_f32_16x16x32_f16 at a sixteenth of the cost each.  At 64
+  // matrices the tile update was the throughput-bound half of a {D, U} launch (profiles/r05_du_split.txt: 19 of 52.6 us).
+  //   * the rotation matrices come from the fp16 hi / lo log (Qr16: the fragments the V pass reads; absolute resolution 2^-25
+  //     of entries bounded by 1 -- relative to the rows they multiply, what the fp32 products' own rounding is);
+  //   * X and T are scaled by ONE power of two per tile, s = 2^(11 - e) with max |X_tile| = f 2^e: |X s| <= 2^11, |T s| <= 8 x
+  //     that (a row of X Q_h has the 2-norm of the row of X) < fp16's range; hi + lo then carry 22 significand bits down to an
+  //     absolute 2^-36 of the TILE's largest entry -- a graded matrix's small tiles keep their own relative accuracy;
+  //   * product 1, T = X Q_h: A = the wave's 16-row strip of X split in registers, B = Q_h's fragments staged once per block in
+  //     LDS; the accumulator layout (lane (n, g), register r <-> T[16 ti + 4 g + r][16 tj + n]) IS one half of lane (n, g)'s slot
+  //     of product 2's B fragment (qfrag16_k: elements 4 (ti & 1) + r of fragment (tj, ti >> 1)), so T goes to LDS as split
+  //     fragments with 8-byte stores from the lane that computed it -- no transpose, no second scaling;
+  //   * product 2, Y = Q_g^T T: A = the wave's quarter of Q_g's fragments straight from the log, B = T's fragments from LDS;
+  //     the output mapping is the fp32 path's (lane: four consecutive rows of one column), Y = acc / s exactly.
+  // 32.8 KB of LDS (33.8 before), two barriers as before.
+  constexpr int NCH = M2 / 32;
+  half_t* Qh16 = reinterpret_cast<half_t*>(jsm);                 // [(tj * NCH + c) * 2 + part][64][8]: the fragments of pair h
+  half_t* T16 = Qh16 + 2 * FR;                                    // the same layout: T = X Q_h as split B fragments
+  float* wmax = reinterpret_cast<float*>(T16 + 2 * FR);           // [4] the waves' strip maxima
+  half8 gq[NCH][2];                                               // Q_g, output-row tile ti: A fragments (chunk, hi | lo)
+  f32x4 xv[NCH][2];
+  {
+    const float* Xrow = p.Pr + m * cc + (size_t)pair_index<B>(16 * ti + li, gi, gj) * C;
+    const half_t* g16 = p.Qr16 + ((size_t)m * npair + g) * (2 * FR);
+    const half_t* h16 = p.Qr16 + ((size_t)m * npair + h) * (2 * FR);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        xv[c][hf] = *reinterpret_cast<const f32x4*>(Xrow + pair_index<B>(qfrag16_k<M2>(c, lq, 4 * hf), hi, hj));
+        gq[c][hf] = *reinterpret_cast<const half8*>(g16 + ((size_t)((ti * NCH + c) * 2 + hf) * 64 + lane) * 8);
+      }
+    half8 hv[2 * FR / 8 / NT];
+#pragma unroll
+    for (int i = 0; i < 2 * FR / 8 / NT; ++i) hv[i] = *reinterpret_cast<const half8*>(h16 + (size_t)(tid + i * NT) * 8);
+#pragma unroll
+    for (int i = 0; i < 2 * FR / 8 / NT; ++i) *reinterpret_cast<half8*>(Qh16 + (size_t)(tid + i * NT) * 8) = hv[i];
+    float mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fabsf(xv[c][hf][j]));
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) wmax[wave] = mx;
+  }
+  __syncthreads();
+  float sc = 1.f, isc = 1.f;
+  {
+    const float mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (mx > 0.f && mx < 3.0e38f) {
+      int e;
+      frexpf(mx, &e);
+      e = e < -100 ? -100 : e;                                    // (a tile of denormal dust: the scale stays finite)
+      sc = ldexpf(1.f, 11 - e);
+      isc = ldexpf(1.f, e - 11);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {                                 // T = X Q_h
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = xv[c][j >> 2][j & 3] * sc;
+    half8 ah, al;
+    split_f16x8(x, ah, al);
+#pragma unroll
+    for (int tj = 0; tj < NW; ++tj) {
+      const half8 bh = *reinterpret_cast<const half8*>(Qh16 + ((size_t)((tj * NCH + c) * 2 + 0) * 64 + lane) * 8);
+      const half8 bl = *reinterpret_cast<const half8*>(Qh16 + ((size_t)((tj * NCH + c) * 2 + 1) * 64 + lane) * 8);
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[tj], 0, 0, 0);
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[tj], 0, 0, 0);
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[tj], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int tj = 0; tj < NW; ++tj) {         // the lane holds (T s)[16 ti + 4 lq + r][16 tj + li]: elements 4 (ti & 1) + r of its own slot
+    typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+    half4v th, tl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      th[r] = (half_t)acc[tj][r];
+      tl[r] = (half_t)(acc[tj][r] - (float)th[r]);
+    }
+    half_t* slot = T16 + ((size_t)((tj * NCH + (ti >> 1)) * 2) * 64 + lane) * 8 + 4 * (ti & 1);
+    *reinterpret_cast<half4v*>(slot) = th;
+    *reinterpret_cast<half4v*>(slot + 64 * 8) = tl;
+    acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)             // Y = Q_g^T T: rows 16 ti .. of Y (the columns 16 ti .. of Q_g)
+#pragma unroll
+    for (int tj = 0; tj < NW; ++tj) {
+      const half8 bh = *reinterpret_cast<const half8*>(T16 + ((size_t)((tj * NCH + c) * 2 + 0) * 64 + lane) * 8);
+      const half8 bl = *reinterpret_cast<const half8*>(T16 + ((size_t)((tj * NCH + c) * 2 + 1) * 64 + lane) * 8);
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gq[c][1], bh, acc[tj], 0, 0, 0);
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gq[c][0], bl, acc[tj], 0, 0, 0);
+      acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gq[c][0], bh, acc[tj], 0, 0, 0);
+    }
+#pragma unroll
+  for (int tj = 0; tj < NW; ++tj)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[tj][r] *= isc;
+#else
   float* Qh = jsm;                                  // [FR] the log of pair h, unit order
   float* Tt = jsm + FR;                             // [M2][P4] T transposed
   f32x4 xa[NW], ga[NW];
@@ -1143,6 +1249,7 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
       for (int tj = 0; tj < NW; ++tj)
         acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[gg][sx], b4[tj][sx], acc[tj], 0, 0, 0);
   }
+#endif
   float* Pw = p.Pw + m * cc;
 #pragma unroll
   for (int tj = 0; tj < NW; ++tj) {

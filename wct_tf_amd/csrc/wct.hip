@@ -1428,9 +1428,10 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
 }
 
 // grid (matrices), one wave: the measurement's sums over the tiles, then the test (ck.mid: the one in the middle of a sweep)
-__global__ __launch_bounds__(64) void jacobi_check_kernel(JacobiState* st, const float* partial, int ntile, float mixed_w, JacobiCheckArgs ck) {
+__global__ __launch_bounds__(64) void jacobi_check_kernel(JacobiState* st, const float* partial, int ntile, float mixed_w, JacobiCheckArgs ck,
+                                                          int* done_host /* this group's mapped host words, or null */) {
   const int m = blockIdx.x, tid = threadIdx.x;
-  if (st[m].done) return;
+  if (st[m].done) { if (tid == 0 && done_host) done_host[m] = st[m].done; return; }
   float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* pm = partial + (size_t)m * JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE;
   for (int tt = tid; tt < ntile; tt += 64)
@@ -1445,6 +1446,7 @@ __global__ __launch_bounds__(64) void jacobi_check_kernel(JacobiState* st, const
     st[m].pad2 = near_m ? 1 : 0;
     const float vv[4] = {(near_m ? mixed_w : 1.f) * a[0] + mixed_w * a[1], a[2], a[3], a[4]};
     if (ck.mid) jacobi_check_mid(st[m], vv, ck); else jacobi_check_end(st[m], vv, ck);
+    if (done_host) done_host[m] = st[m].done;
   }
 }
 
@@ -1518,6 +1520,7 @@ struct JacobiGroup {
                                              // consecutive steps, the two matrix buffers (P[0] = A)
   int cur, par, lg, segs;                    // buffer holding the matrices; generation of the last pair problems; log in use;
                                              // segments completed
+  int* done_host = nullptr;                  // the group's slot of JacobiHost::flags_dev (jacobi_check_kernel), or null
   int vstrip;                                // V is updated per segment by jacobi_vstrip_kernel on the side stream `vs`
   hipStream_t vs; hipEvent_t ev_seg, ev_v[2];// main -> side (segment enqueued), side -> main (log buffer free again)
   bool v_busy[2];
@@ -1530,7 +1533,10 @@ struct JacobiGroup {
 // per host thread (= per ctx user): pinned copies of the groups' convergence flags and one event per group
 // (events belong to the device that was current when they were created: one set per device, so that a thread driving
 //  contexts on several GPUs never records an event of GPU 0 on a stream of GPU 1 -- ADVICE r2)
-struct JacobiHost { JacobiState* flags; hipEvent_t ev[4]; hipStream_t vs[4]; hipEvent_t ev_seg[4], ev_v[4][2]; };
+// flags: the `done` words of the groups' matrices, host memory MAPPED into the device ([4 groups][64]): jacobi_check_kernel stores
+// them there itself, and the host reads them after the sweep's event -- up to round 5 a device-to-host copy of the JacobiState
+// array per group and sweep carried them (45 copy kernels of ~5 us per step in the solver's launch trains, at every batch size)
+struct JacobiHost { int* flags; int* flags_dev; hipEvent_t ev[4]; hipStream_t vs[4]; hipEvent_t ev_seg[4], ev_v[4][2]; };
 static JacobiHost* jacobi_host() {
   constexpr int MAXDEV = 16;
   static thread_local JacobiHost hs[MAXDEV] = {};
@@ -1538,7 +1544,8 @@ static JacobiHost* jacobi_host() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
   JacobiHost& h = hs[dev];
   if (!h.flags) {
-    if (hipHostMalloc((void**)&h.flags, 4 * 64 * sizeof(JacobiState)) != hipSuccess) { h.flags = nullptr; return nullptr; }
+    if (hipHostMalloc((void**)&h.flags, 4 * 64 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&h.flags_dev, h.flags, 0) != hipSuccess) { h.flags = nullptr; return nullptr; }
     bool ok = true;
     // (tuning builds: WCT_JACOBI_VPRIO = 1 / 2 puts the V-pass streams at the lowest / highest stream priority.  Measured, either
     //  way: the eigensolver 12.2 -> 22 ms per 32-pair step, nothing at 8 pairs where the V pass does not run -- profiles/r05_vprio.txt)
@@ -1727,7 +1734,7 @@ static void jacobi_measure(JacobiGroup& G, int C, const JacobiCheckArgs& ck) {
   const int ntr = (C + JACOBI_RESID_T - 1) / JACOBI_RESID_T;
   const int ntile = ntr * (ntr + 1) / 2;
   hipLaunchKernelGGL(jacobi_resid_kernel, dim3(ntile, G.nmat), dim3(256), 0, G.stream, G.P[G.cur], G.st, G.resid, C);
-  hipLaunchKernelGGL(jacobi_check_kernel, dim3(G.nmat), dim3(64), 0, G.stream, G.st, G.resid, ntile, G.tol_fn > 2e-2f ? 7.1f : 1.f, ck);
+  hipLaunchKernelGGL(jacobi_check_kernel, dim3(G.nmat), dim3(64), 0, G.stream, G.st, G.resid, ntile, G.tol_fn > 2e-2f ? 7.1f : 1.f, ck, G.done_host);
   LAUNCH_NOTE("jacobi_resid_kernel / jacobi_check_kernel");
 }
 
@@ -1749,6 +1756,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     G.cur = 0; G.par = 0; G.lg = 0; G.segs = 0; G.v_busy[0] = G.v_busy[1] = false;
     G.vstrip = host && g < 4 && vstrip_supported<M2>(C) && (vs_env == 2 || (vs_env == 1 && G.nmat >= vs_min && C >= 256));
     if (G.vstrip) { G.vs = host->vs[g]; G.ev_seg = host->ev_seg[g]; G.ev_v[0] = host->ev_v[g][0]; G.ev_v[1] = host->ev_v[g][1]; }
+    G.done_host = host && g < 4 ? host->flags_dev + g * 64 : nullptr;
     hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, G.nmat), dim3(256), 0, G.stream, G.A, G.V, G.st, C, G.mat0, G.shared_style);
     HIP_TRY(hipGetLastError());
   }
@@ -1767,7 +1775,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
       bool all = true;
       for (int g = 0; g < ngrp; ++g) {
         HIP_TRY(hipEventSynchronize(host->ev[g]));
-        for (int m = 0; m < grp[g].nmat; ++m) all = all && host->flags[g * 64 + m].done != 0;
+        for (int m = 0; m < grp[g].nmat; ++m) all = all && host->flags[g * 64 + m] != 0;
       }
       pending = false;
       if (all) break;          // every matrix was done before this sweep began: its launches were no-ops
@@ -1788,8 +1796,7 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
       for (int g = 0; g < ngrp; ++g) {
-        HIP_TRY(hipMemcpyAsync(host->flags + g * 64, grp[g].st, grp[g].nmat * sizeof(JacobiState), hipMemcpyDeviceToHost, grp[g].stream));
-        HIP_TRY(hipEventRecord(host->ev[g], grp[g].stream));
+        HIP_TRY(hipEventRecord(host->ev[g], grp[g].stream));      // (behind the sweep's jacobi_check_kernel, which stored the flags)
       }
       pending = true;
     }
