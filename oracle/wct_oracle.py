@@ -169,7 +169,7 @@ def preserve_colors_np(style_rgb, content_rgb):
     return np.uint8(np.clip(coraled, 0, 1) * 255.)
 
 
-def style_swap(content, style, patch_size, stride):
+def style_swap(content, style, patch_size, stride, return_margins=False):
     """Patch swap, semantics of ops.py:220-278 (batch dim dropped: HxWxC in, HxWxC out).
 
     * every patch_size^2 x C patch of `style` at `stride` (VALID) is a filter;
@@ -199,6 +199,10 @@ def style_swap(content, style, patch_size, stride):
             cols_c[y * wo + x] = c[y * st:y * st + p, x * st:x * st + p, :].reshape(-1)
     enc = cols_c @ normed.reshape(rows * cols, -1).T
     arg = np.argmax(enc, axis=1)
+    if return_margins:
+        # test infrastructure: how decided every match is -- (best - second best) / |best| per content position [ho][wo]
+        top2 = np.sort(np.float64(enc), axis=1)[:, -2:]
+        margins = ((top2[:, 1] - top2[:, 0]) / np.maximum(np.abs(top2[:, 1]), 1e-30)).reshape(ho, wo)
     hd, wd = (ho - 1) * st + p, (wo - 1) * st + p
     dec = np.zeros((hd, wd, ch), np.float32)
     cnt = np.zeros((hd, wd, 1), np.float32)
@@ -206,10 +210,10 @@ def style_swap(content, style, patch_size, stride):
         for x in range(wo):
             dec[y * st:y * st + p, x * st:x * st + p, :] += patches[arg[y * wo + x]]
             cnt[y * st:y * st + p, x * st:x * st + p, :] += 1
-    return dec / cnt
+    return (dec / cnt, margins) if return_margins else dec / cnt
 
 
-def wct_style_swap(content, style, alpha, patch_size=3, stride=1, eps=1e-8):
+def wct_style_swap(content, style, alpha, patch_size=3, stride=1, eps=1e-8, return_margins=False):
     """ops.py:145-218: whiten content and style (S^-1/2, no eps in the gains; eps*I on the covariances),
     style_swap on the whitened maps, colour with the style's S^1/2, add the style mean, blend with the
     un-centred content (ops.py:210)."""
@@ -231,7 +235,9 @@ def wct_style_swap(content, style, alpha, patch_size=3, stride=1, eps=1e-8):
     ws_mat = us[:, :ks].dot(np.diag(ss[:ks] ** np.float32(-0.5))).dot(us[:, :ks].T)
     whiten_c = _unflatten(wc_mat.dot(fc), cshape)[0]
     whiten_s = _unflatten(ws_mat.dot(fs), sshape)[0]
-    swapped = style_swap(whiten_c, whiten_s, patch_size, stride)
+    swapped = style_swap(whiten_c, whiten_s, patch_size, stride, return_margins)
+    if return_margins:
+        swapped, margins = swapped
     hcw = cshape[0] * cshape[1]
     if swapped.shape[0] * swapped.shape[1] != hcw:
         raise ValueError('style-swap output %s does not match the content map %s: pre-size the content '
@@ -240,4 +246,5 @@ def wct_style_swap(content, style, alpha, patch_size=3, stride=1, eps=1e-8):
     col = us[:, :ks].dot(np.diag(ss[:ks] ** np.float32(0.5))).dot(us[:, :ks].T)
     fcs = col.dot(ssf) + ms
     blended = np.float32(alpha) * fcs + np.float32(1 - alpha) * (fc + mc)
-    return np.float32(_unflatten(blended, cshape))
+    out = np.float32(_unflatten(blended, cshape))
+    return (out, margins) if return_margins else out

@@ -514,13 +514,21 @@ def test_style_swap(ctx, c, hc, wc, hs, ws, p, st):
     from wct_tf_amd import ops
     fc = synthetic_features(90 + c, c, hc, wc, 1.5)
     fs = synthetic_features(95 + c, c, hs, ws, 1.5)
-    want = oracle.wct_style_swap(fc, fs, 0.6, p, st)
+    want, margins = oracle.wct_style_swap(fc, fs, 0.6, p, st, return_margins=True)
     got = ops.wct_style_swap(fc, fs, 0.6, p, st, ctx=ctx)
     e = rel_err(got, want)
-    # a near-tie in the patch correlation may legitimately pick another patch: count differing pixels
-    diff_px = (np.abs(got - want).max(-1) > 1e-3 * np.abs(want).max()).mean()
-    print('style_swap C=%d %dx%d p=%d st=%d: rel %.2e, pixels differing %.4f' % (c, hc, wc, p, st, e, diff_px))
+    # The patch match is an argmax over correlations of WHITENED features, which this path has to ~1e-4 (the transform's own
+    # error on these features: 2.4e-4, tools/probe/r06_swap_margin.py): a match the oracle itself decides by less than 1e-3 of the
+    # correlation may legitimately go to the runner-up.  Round 6: quantified with the oracle's margins instead of "< 1 % of the
+    # pixels" -- every pixel that differs must lie in the p x p footprint of such a near-tie position, and nowhere else.
+    diff = np.abs(got - want).max(-1) > 1e-3 * np.abs(want).max()
+    near = np.zeros(diff.shape, bool)
+    for y, x in zip(*np.nonzero(margins < 1e-3)):
+        near[y * st:y * st + p, x * st:x * st + p] = True
+    print('style_swap C=%d %dx%d p=%d st=%d: rel %.2e, pixels differing %d (positions the oracle decides by < 1e-3: %d of %d; smallest margin %.1e)'
+          % (c, hc, wc, p, st, e, int(diff.sum()), int((margins < 1e-3).sum()), margins.size, margins.min()))
     assert got.shape == want.shape
-    assert e < 1e-3 or diff_px < 0.01
+    assert e < 1e-3 or not np.any(diff & ~near), int((diff & ~near).sum())
+    assert diff.mean() < 0.05
     with pytest.raises(Exception):
         ops.wct_style_swap(synthetic_features(1, 64, 12, 12), fs[:, :9, :9, :64] if c == 64 else synthetic_features(2, 64, 9, 9), 0.6, 3, 2, ctx=ctx)   # 12 does not survive stride 2

@@ -2485,18 +2485,21 @@ static int launch_means(const float* content, int Nc, const float* style, int Ns
 // refresh (see refresh_needed): X = A0 V, then A <- V^T X, for the matrices whose kept spectrum reaches 4 decades below their
 // norm; the others' blocks exit at once.  Before ANY spectral function of the tracked (A, V): launch_wct's apply stage and the
 // three of launch_style_swap (relu5_1, C = 512: every input of 352 x 352 or smaller has N < C -- the rank-deficient case).
-static int launch_refresh(const WctCarve& w, int C, int P, int shared_style, hipStream_t s) {
+// always: every matrix, whatever its spectrum (measured for style-swap when the solver's tile update moved to split fp16: the
+// 3 of 900 patch matches that flipped on the 32 x 32 test case flipped with the rotated matrix recomputed as well -- it is V, not
+// the tracked matrix, that carries the difference; the switch stays for experiments).
+static int launch_refresh(const WctCarve& w, int C, int P, int shared_style, hipStream_t s, bool always = false) {
   const size_t cc = (size_t)C * C;
   int rc;
   GemmArgs r1 = {};
   r1.A = w.A0; r1.lda = C; r1.a_kmajor = 0; r1.B = w.V; r1.ldb = C; r1.b_kmajor = 1; r1.sA = r1.sB = cc; r1.skip_shared = shared_style;
   r1.M = C; r1.N = C; r1.K = C; r1.ksplit = C; r1.out32 = w.X; r1.ldo = C; r1.s_out = cc;
-  r1.mask_diag = w.A; r1.s_mask = cc; r1.mask_out = w.refresh;
+  if (!always) { r1.mask_diag = w.A; r1.s_mask = cc; r1.mask_out = w.refresh; }
   if ((rc = launch_gemm(r1, 1, 2 * P, s))) return rc;
   GemmArgs r2 = {};
   r2.A = w.V; r2.lda = C; r2.a_kmajor = 1; r2.B = w.X; r2.ldb = C; r2.b_kmajor = 1; r2.sA = r2.sB = cc; r2.skip_shared = shared_style;
   r2.M = C; r2.N = C; r2.K = C; r2.ksplit = C; r2.out32 = w.A; r2.ldo = C; r2.s_out = cc;
-  r2.mask_in = w.refresh;
+  if (!always) r2.mask_in = w.refresh;
   return launch_gemm(r2, 1, 2 * P, s);
 }
 
