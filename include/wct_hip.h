@@ -192,9 +192,11 @@ int wct_d2h(wct_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
  * class ids: 0 conv3x3 (MFMA), 1 conv_first, 2 conv_last, 3 pool, 4 wct stats+cov,
  * 5 jacobi eigensolver, 6 wct tbuild+apply, 7 other, 8 conv12 (conv1_1 + conv1_2 + pool in one
  * launch: the content passes of the levels >= 2), 9 conv_wino (the 3x3 launches the reduced-FLOP kernel takes -- csrc/conv_wino.hip,
- * the >= 256-channel layers without a feature tap; flops are the DIRECT convolution's, the kernel executes 2/3 of them).  When
- * enabled every launch group is bracketed by hipEventRecord on the ctx stream; wct_prof_read syncs and accumulates. */
-#define WCT_PROF_CLASSES 10
+ * the >= 256-channel layers without a feature tap; flops are the DIRECT convolution's, the kernel executes 2/3 of them), 10
+ * conv_tail (the last 64 -> 64 conv of a decoder + the 64 -> 3 output conv in one launch, csrc/conv_tail.hip; flops of the two
+ * layers, the halo recomputation not counted).  When enabled every launch group is bracketed by hipEventRecord on the ctx stream;
+ * wct_prof_read syncs and accumulates. */
+#define WCT_PROF_CLASSES 11
 int wct_prof_enable(wct_ctx* ctx, int on);
 int wct_prof_reset(wct_ctx* ctx);
 int wct_prof_read(wct_ctx* ctx, double ms[WCT_PROF_CLASSES], long long launches[WCT_PROF_CLASSES],

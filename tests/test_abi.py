@@ -166,6 +166,6 @@ def test_profiling_class_list_matches_the_header():
     from wct_tf_amd import _lib
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'wct_hip.h')).read()
     n = int(re.search(r'#define\s+WCT_PROF_CLASSES\s+(\d+)', hdr).group(1))
-    assert n == len(_lib.PROF_CLASSES) == 10
+    assert n == len(_lib.PROF_CLASSES) == 11
     assert _lib.PROF_CLASSES[0] == 'conv3x3' and _lib.PROF_CLASSES[8] == 'conv12'
     assert len(set(_lib.PROF_CLASSES)) == n

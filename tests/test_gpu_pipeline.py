@@ -984,3 +984,37 @@ def test_conv1_1_inside_conv1_2s_patch_loader_gives_the_bits_of_the_two_launches
                 n += 1
     assert n >= 11
     assert np.array_equal(ctx.stylize_batch(cs, st, RELU_TARGETS, alpha=0.8), ref['frames'])
+
+
+def test_decoder_tail_in_one_launch_gives_the_bits_of_the_two_launches(ctx, weights, tmp_path):
+    """Every decoder ends in a 64 -> 64 conv (its input x2-upsampled from relu2_1 up) and the 64 -> 3 output conv (model.py:283-298);
+    csrc/conv_tail.hip runs the two as ONE launch with the 64-channel map in LDS.  The decoded images and the
+    frames must be the ones of the two-launch path (WCT_FUSE_TAIL=0, read once per process: a subprocess), bit for bit: every
+    decoder, full tiles, ragged tiles in both directions, maps smaller than a tile, the reflected borders, a batch."""
+    import subprocess, sys
+    rng = np.random.default_rng(12)
+    feats = {}
+    for lv, c, sizes in (('relu1_1', 64, [(48, 32), (37, 29), (5, 3), (16, 16)]), ('relu2_1', 128, [(24, 40), (9, 7), (2, 3)]),
+                         ('relu3_1', 256, [(8, 12), (3, 5)]), ('relu4_1', 512, [(6, 4)]), ('relu5_1', 512, [(3, 2)])):
+        for i, (h, w) in enumerate(sizes):
+            feats['%s/%d' % (lv, i)] = np.maximum(rng.standard_normal((h, w, c)), 0).astype(np.float32)
+    cs = rng.integers(0, 256, (3, 96, 80, 3), dtype=np.uint8)
+    st = rng.integers(0, 256, (72, 64, 3), dtype=np.uint8)
+    np.savez(tmp_path / 'in.npz', cs=cs, st=st, **feats)
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from wct_tf_amd.context import Context\n"
+        "from wct_tf_amd.weights import synthetic_weights, RELU_TARGETS\n"
+        "d = np.load(%r)\n"
+        "c = Context(0); c.set_weights(synthetic_weights(seed=42))\n"
+        "out = {k: c.decode(d[k], k.split('/')[0]) for k in d.files if '/' in k}\n"
+        "out['frames'] = c.stylize_batch(d['cs'], d['st'], RELU_TARGETS, alpha=0.8)\n"
+        "np.savez(%r, **out)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / 'in.npz'), str(tmp_path / 'out.npz')))
+    subprocess.run([sys.executable, '-c', script], check=True, env=dict(os.environ, WCT_FUSE_TAIL='0'), timeout=600)
+    ref = np.load(tmp_path / 'out.npz')
+    for k, f in feats.items():
+        got = ctx.decode(f, k.split('/')[0])
+        assert got.shape == ref[k].shape and np.abs(got).max() > 0
+        assert np.array_equal(got, ref[k]), (k, float(np.abs(got - ref[k]).max()))
+    assert np.array_equal(ctx.stylize_batch(cs, st, RELU_TARGETS, alpha=0.8), ref['frames'])

@@ -62,7 +62,7 @@ SIGNATURES = [
 
 WCT_NP, WCT_TF = 0, 1
 FLAG_ADAIN, FLAG_MODE_NP, FLAG_SWAP5, FLAG_STYLE_SHARED, FLAG_IMAGES_F32 = 1, 2, 4, 8, 16
-PROF_CLASSES = ['conv3x3', 'conv_first', 'conv_last', 'pool', 'wct_cov', 'jacobi', 'wct_apply', 'other', 'conv12', 'conv_wino']
+PROF_CLASSES = ['conv3x3', 'conv_first', 'conv_last', 'pool', 'wct_cov', 'jacobi', 'wct_apply', 'other', 'conv12', 'conv_wino', 'conv_tail']
 
 _lib = None
 

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libwct_hip.so')
-SOURCES = ['api.hip', 'conv.hip', 'conv_wino.hip', 'wct.hip', 'coral.hip', 'train.hip']
+SOURCES = ['api.hip', 'conv.hip', 'conv_wino.hip', 'conv_tail.hip', 'wct.hip', 'coral.hip', 'train.hip']
 
 
 STAMP = LIB + '.src.sha256'

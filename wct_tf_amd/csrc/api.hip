@@ -623,8 +623,23 @@ static int run_decoder(wct_ctx* c, int level, const half_t* feat16, int B, int h
   const half_t* cur = feat16;
   half_t* bufs[2] = {(half_t*)c->act[0].p, (half_t*)c->act[1].p};
   int which = 0, ci = 0, up = 0;
-  for (auto& s : d.plan) {
+  // the last 64 -> 64 conv and the 64 -> 3 output conv as one launch (csrc/conv_tail.hip): the 64-channel full-resolution map is
+  // neither written nor read, and the bits are the same.  (WCT_FUSE_TAIL=0: the two launches; test hook, read once per process)
+  static const int fuse_tail_env = getenv("WCT_FUSE_TAIL") ? atoi(getenv("WCT_FUSE_TAIL")) : 1;
+  const size_t nsteps = d.plan.size();
+  for (size_t si = 0; si < nsteps; ++si) {
+    const PlanStep& s = d.plan[si];
     if (s.kind == 'U') { up = 1; h *= 2; w *= 2; continue; }
+    if (fuse_tail_env && !c->no_wino /* (the training forward keeps every activation) */ && s.cin == 64 && s.cout == 64 &&
+        si + 1 < nsteps && d.plan[si + 1].kind == 'C' && d.plan[si + 1].cout == 3) {
+      const ConvLayer& l = d.convs[ci++];
+      ConvTailArgs a;
+      a.x = cur; a.w = l.w; a.bias = l.b; a.wlast = d.last_w; a.blast = d.last_b; a.y = img_out; a.B = B; a.H = h; a.W = w; a.upsample = up;
+      const double px = (double)B * h * w;
+      ProfScope ps(c, 10, 2.0 * px * (9 * 64 * 64 + 576 * 3), px * ((up ? 32 : 128) + 12) + 9.0 * 64 * 64 * 2);
+      TRY(launch_conv_tail(a, c->stream));
+      break;
+    }
     if (s.cout == 3) {
       ARG_CHECK(up == 0);
       ConvLastArgs a;

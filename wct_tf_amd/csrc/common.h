@@ -43,8 +43,9 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // numerics of a library whose contract is bit-reproducible output.  Only a -DWCT_TUNING build (tools/, experiments on the
 // GPU box) reads them from the environment.  THREE documented TEST hooks stay live in every build, all safe by
 // construction: WCT_JACOBI_MAX_SWEEPS can only LOWER the sweep budget (clamped to the compiled one; the solve then fails
-// loudly, never silently); WCT_FUSE_STATS=0 and WCT_FUSE_CONV1=0 each select a path whose output is bit-identical
-// (asserted by tests/test_gpu_pipeline.py).  grep getenv: these three and nothing else outside #ifdef WCT_TUNING.
+// loudly, never silently); WCT_FUSE_STATS=0, WCT_FUSE_CONV1=0 and WCT_FUSE_TAIL=0 each select a path whose output is
+// bit-identical (asserted by tests/test_gpu_pipeline.py); WCT_WINOGRAD=0 keeps every 3x3 layer on the direct kernel (the
+// round-5 arithmetic: other roundings, same tolerances).  grep getenv: these five and nothing else outside #ifdef WCT_TUNING.
 #ifdef WCT_TUNING
 #include <stdlib.h>
 static inline int tune_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
@@ -148,6 +149,19 @@ struct ConvLastArgs {    // 64 -> 3, no activation (model.py:298)
   int B, H, W;
 };
 int launch_conv_last(const ConvLastArgs& a, hipStream_t s);
+
+// conv_tail.hip: the last 64 -> 64 conv of a decoder (ReLU; its input x2-upsampled if `upsample`) and the 64 -> 3 output conv in one
+// kernel -- the 64-channel full-resolution map stays in LDS.  The bits of launch_conv3x3 + launch_conv_last.
+struct ConvTailArgs {
+  const half_t* x;      // [B][Hin][Win][64] fp16 (Hin = H / 2 if upsample)
+  const half_t* w;      // the 64 -> 64 conv's fragments (ConvArgs::w)
+  const float* bias;    // [64]
+  const half_t* wlast;  // the output conv's fragments (ConvLastArgs::wfrag)
+  const float* blast;   // [3]
+  float* y;             // [B][H][W][3] fp32, unclipped
+  int B, H, W, upsample;
+};
+int launch_conv_tail(const ConvTailArgs& a, hipStream_t s);
 
 int launch_maxpool2x2(const half_t* x, half_t* y, int B, int H, int W, int C, hipStream_t s);
 int launch_u8_to_f32(const uint8_t* x, float* y, size_t n, hipStream_t s);       // /255 (wct.py:64)
