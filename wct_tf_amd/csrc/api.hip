@@ -623,9 +623,12 @@ static int run_decoder(wct_ctx* c, int level, const half_t* feat16, int B, int h
   const half_t* cur = feat16;
   half_t* bufs[2] = {(half_t*)c->act[0].p, (half_t*)c->act[1].p};
   int which = 0, ci = 0, up = 0;
-  // the last 64 -> 64 conv and the 64 -> 3 output conv as one launch (csrc/conv_tail.hip): the 64-channel full-resolution map is
-  // neither written nor read, and the bits are the same.  (WCT_FUSE_TAIL=0: the two launches; test hook, read once per process)
-  static const int fuse_tail_env = getenv("WCT_FUSE_TAIL") ? atoi(getenv("WCT_FUSE_TAIL")) : 1;
+  // WCT_FUSE_TAIL=1 (test hook, read once per process): the last 64 -> 64 conv and the 64 -> 3 output conv as ONE launch
+  // (csrc/conv_tail.hip): the 64-channel full-resolution map is neither written nor read, and the bits are the same.  NOT the
+  // default: measured on one box (profiles/r06_conv_tail.txt) the fused launch takes what the two launches take (+0.25 ms per
+  // 32-pair step) -- the 64 -> 64 layer is bound by MFMA work and per-tile fixed costs, not by the bytes the fusion removes, and
+  // the 18 x 18 halo costs 1.37 x its MFMA work.
+  static const int fuse_tail_env = getenv("WCT_FUSE_TAIL") ? atoi(getenv("WCT_FUSE_TAIL")) : 0;
   const size_t nsteps = d.plan.size();
   for (size_t si = 0; si < nsteps; ++si) {
     const PlanStep& s = d.plan[si];

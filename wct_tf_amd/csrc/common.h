@@ -43,7 +43,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // numerics of a library whose contract is bit-reproducible output.  Only a -DWCT_TUNING build (tools/, experiments on the
 // GPU box) reads them from the environment.  THREE documented TEST hooks stay live in every build, all safe by
 // construction: WCT_JACOBI_MAX_SWEEPS can only LOWER the sweep budget (clamped to the compiled one; the solve then fails
-// loudly, never silently); WCT_FUSE_STATS=0, WCT_FUSE_CONV1=0 and WCT_FUSE_TAIL=0 each select a path whose output is
+// loudly, never silently); WCT_FUSE_STATS=0, WCT_FUSE_CONV1=0 and WCT_FUSE_TAIL=1 each select a path whose output is
 // bit-identical (asserted by tests/test_gpu_pipeline.py); WCT_WINOGRAD=0 keeps every 3x3 layer on the direct kernel (the
 // round-5 arithmetic: other roundings, same tolerances).  grep getenv: these five and nothing else outside #ifdef WCT_TUNING.
 #ifdef WCT_TUNING
