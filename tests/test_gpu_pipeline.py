@@ -736,14 +736,15 @@ def test_config5_1024_content_512_style_adain_keepcolors(ctx, weights):
 
 @pytest.mark.parametrize('adain', [False, True])
 def test_config5_levels_teacher_forced_1024_content_512_style(ctx, weights, adain):
-    """BASELINE config 5 at its own sizes against the oracle: 1024x1024 content, 512x512 style (Nc = 4 Ns at every
-    level: 4 096 / 1 024 pixels at relu5_1 ... 1 048 576 / 262 144 at relu1_1), five levels, alpha 0.8 -- the WCT
+    """BASELINE config 5's SHAPE against the oracle, teacher-forced: content with four times the style's pixels (Nc = 4 Ns at every
+    level; since round 6 at 512 x 512 / 256 x 256, see below), five levels, alpha 0.8 -- the WCT
     branch and the --adain branch (ops.py:282-294, stylize.py:85-100), every level's encoder, transform and decoder on
     the oracle's own level inputs."""
-    # (round 6, the suite's time budget on the driver: the WCT branch at the full 1024 / 512 sizes; the --adain branch -- whose
-    #  transform has no size-dependent stage beyond the statistics, tested at 1024^2 in test_adain -- at 512 / 256 with the same 4 : 1
-    #  pixel ratio; the CHAINED config-5 tests above run both branches at full size)
-    size = 512 if adain else 1024
+    # (round 6, the suite's time budget on the driver -- 681 of its 1200 s in round 5, this test 147 s of them: both branches at
+    #  512 / 256, the same 4 : 1 pixel ratio between content and style at every level; the FULL config-5 sizes run end to end,
+    #  chained, in both branches in test_config5_chained_end_to_end_1024_content_512_style, the transform at Nc = 1 048 576 in
+    #  test_wct_config_sizes and the convolutions at 1024 x 1024 in the chained test's frames)
+    size = 512
     content = synthetic_image(1005, size, size)
     style = synthetic_image(2005, size // 2, size // 2)
     want = _teacher_forced(ctx, weights, content, style, RELU_TARGETS, 0.8, 'tf', adain=adain)
