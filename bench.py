@@ -118,7 +118,7 @@ def pmc_traffic(batch, size):
     """HBM bytes per conv3x3 launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in separate
     runs, gfx950 correction applied by tools/summarize_prof.py).  PMC counters cannot be read from inside this
     process, so the figure is the profile of this exact workload, not a measurement of this run; null otherwise."""
-    for tag in ('r05_final', 'r04_final', 'r03_final', 'r02_final', 'r01_final'):
+    for tag in ('r06_final', 'r05_final', 'r04_final', 'r03_final', 'r02_final', 'r01_final'):
         path = os.path.join(ROOT, 'profiles', '%s_pmc_conv3x3.json' % tag)
         if batch == PMC_BATCH and size == 512 and os.path.exists(path):
             return json.load(open(path))['hbm_bytes_per_launch_corrected'], 'profiles/%s_pmc_hbm.csv' % tag
@@ -140,9 +140,13 @@ def cpu_baseline(size, weights, alpha):
     # path) the transform timed is the reference's OWN wct_np, lifted out of its ops.py and executed -- wct_np(eps=0) +
     # (1 - alpha) mc is the graph's wct_tf (tests/golden/wct_tf_reference.npz pins that) -- `kind: reference`; on a box
     # without the tree (the GPU box) it is the restatement oracle.wct_tf -- `kind: port`.
-    transform, kind = None, 'port'
-    ref_ops = os.path.join(os.environ.get('WCT_REFERENCE', '/root/reference'), 'ops.py')
-    if os.path.exists(ref_ops):
+    # (executing code lifted from an untrusted tree is OPT-IN -- WCT_REFERENCE must name the tree; without it, or if
+    #  the lift fails, the restatement runs and the line says why.  eps: wct_np(eps=0) has no 1e-8 on the covariance diagonals,
+    #  the graph's wct_tf has; worth 0.5e-8 / lambda_min in a gain, nothing in a timing.)
+    transform, kind, why = None, 'port', 'WCT_REFERENCE not set: the restatement (oracle.wct_tf)'
+    ref_root = os.environ.get('WCT_REFERENCE')
+    if ref_root:
+        ref_ops = os.path.join(ref_root, 'ops.py')
         try:
             from oracle.make_golden import lift_function
             ref_wct_np = lift_function(ref_ops, 'wct_np')
@@ -150,9 +154,9 @@ def cpu_baseline(size, weights, alpha):
             def transform(fc, fs, a):
                 mc = fc.reshape(-1, fc.shape[-1]).mean(0, dtype=np.float32)
                 return np.float32(ref_wct_np(fc[None], fs[None], a, 0.0) + np.float32(1 - a) * mc)
-            kind = 'reference'
-        except Exception:
-            transform, kind = None, 'port'
+            kind, why = 'reference', 'wct_np lifted from %s' % ref_ops
+        except Exception as e:
+            transform, kind, why = None, 'port', 'lifting wct_np from %s failed (%s: %s): the restatement (oracle.wct_tf)' % (ref_ops, type(e).__name__, e)
     path.stylize(c, s, LEVELS, alpha, 'tf', transform=transform)
     times, t_transform = [], []
     for _ in range(5):
@@ -174,7 +178,7 @@ def cpu_baseline(size, weights, alpha):
             'host_cores': os.cpu_count(), 'torch_threads': torch.get_num_threads(), 'blas_threads': blas,
             # part (i), the reference's transform in NumPy (five whiten-colour transforms per frame, LAPACK
             # SVD), reported separately from part (ii), the torch-CPU stand-in for the CPU-TF conv stack
-            'transform_s': med_t, 'conv_standin_s': med - med_t,
+            'transform_s': med_t, 'conv_standin_s': med - med_t, 'transform_source': why,
             'sample': '1 warm-up + median of 5 frames %dx%d, 5-level, alpha %.1f: NumPy transform (%s) + torch-CPU stand-in for the '
                       'CPU-TF conv stack; %.2f s per frame (min %.2f, max %.2f)' % (size, size, alpha, what, med, min(times), max(times))}
 
