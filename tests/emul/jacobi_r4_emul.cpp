@@ -148,6 +148,9 @@ struct Solver {
     JacobiFusedArgs a;
     a.Pr = P[cur].data(); a.Pw = P[cur ^ 1].data(); a.V = V.data();
     a.Qr = Qlog[lg_u].data(); a.Qw = Qlog[lg_d].data(); a.Qr16 = Q16[lg_u].data(); a.Qw16 = Q16[lg_d].data();
+#ifdef EMUL_U_F16
+    a.u_f16 = 1;                                   // the tile update on split fp16 (the batched transform path's)
+#endif
     a.Sr = Sb[par].data(); a.Sw = Sb[par ^ 1].data();
     a.st = &st; a.C = C; a.nmat = 1; a.step_d = step_d; a.step_u = step_u; a.has_d = has_d; a.has_u = has_u; a.first = first;
     a.with_v = with_v; a.dbg = 0;

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 hypothesis = pytest.importorskip('hypothesis')
-from hypothesis import given, settings, strategies as st, HealthCheck, Phase  # noqa: E402
+from hypothesis import example, given, settings, strategies as st, HealthCheck, Phase  # noqa: E402
 
 import oracle  # noqa: E402
 from conftest import rel_err, max_rel  # noqa: E402
@@ -68,6 +68,7 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     nc, ns = hc * wc, hs * ws
     fc, fs = features(rng, nc, c, scale), features(rng, ns, c, scale * 10.0 ** rng.uniform(-1, 1))
     fn = oracle.wct_np if mode == 'np' else oracle.wct_tf
+    print('wct case: C=%d N=%d/%d (%dx%d, %dx%d) alpha=%r mode=%s log_scale=%r seed=%d' % (c, nc, ns, hc, wc, hs, ws, alpha, mode, log_scale, seed))
     got = ctx.transform(fc, fs, alpha, _lib.WCT_NP if mode == 'np' else _lib.WCT_TF)
     assert np.all(np.isfinite(got))
     # The reference drops eigenvalues <= 1e-5 (absolute, ops.py:68-69 / 112,125).  At tiny feature scales an
@@ -156,6 +157,10 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     assert gpu_exact < max(1e-3, 4 * ref_noise), (c, nc, ns, alpha, mode, log_scale, gpu_exact, ref_noise)
 
 
+# (found by a run of this sweep in round 6 -- the generator's sequence depends on the tests that ran before it in the process -- and
+# kept as an explicit case: N << C at the top of the scale range, rounding noise of the covariance five decades above the cut-off)
+@example(c=256, hc=12, wc=7, hs=13, ws=6, alpha=0.23694110562368303, mode='np', log_scale=3.0, seed=464496)
+@example(c=256, hc=12, wc=7, hs=13, ws=6, alpha=0.9, mode='tf', log_scale=3.0, seed=4)
 @settings(max_examples=30, **COMMON)
 @given(c=st.sampled_from([32, 64, 96, 128, 160, 256]), hc=st.integers(2, 26), wc=st.integers(2, 26),
        hs=st.integers(2, 26), ws=st.integers(2, 26),

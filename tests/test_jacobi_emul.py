@@ -14,11 +14,12 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason='ROCm clang++ not found')
-@pytest.mark.parametrize('variant', [0, 1], ids=['8-strips-4-waves', '16-strips-8-waves'])
-def test_r4_pair_problem_source_emulated_on_the_cpu(tmp_path, variant):
+@pytest.mark.parametrize('variant,u_f16', [(0, 0), (1, 0), (0, 1)], ids=['8-strips-4-waves', '16-strips-8-waves', '8-strips-4-waves-split-fp16-tile-update'])
+def test_r4_pair_problem_source_emulated_on_the_cpu(tmp_path, variant, u_f16):
     exe = str(tmp_path / 'jacobi_r4_emul')
     src = os.path.join(ROOT, 'tests', 'emul', 'jacobi_r4_emul.cpp')
-    subprocess.check_call([CLANG, '-std=c++17', '-O1', '-pthread', '-Wno-unused-value', '-DEMUL_VAR=%d' % variant, '-o', exe, src])
+    subprocess.check_call([CLANG, '-std=c++17', '-O1', '-pthread', '-Wno-unused-value', '-DEMUL_VAR=%d' % variant] + (['-DEMUL_U_F16'] if u_f16 else [])
+                          + ['-o', exe, src])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(out.stdout)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

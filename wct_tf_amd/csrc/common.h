@@ -222,7 +222,9 @@ int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, 
                int* eig_fail /* device-visible status words [4 stream groups][2] (not converged, non-finite), bumped by the
                                 eigensolver, or null */,
                const struct WctFeatStats* stats = nullptr /* unit sums / maxima a conv epilogue left beside the features */);
-enum { WCT_STAGE_COV = 1, WCT_STAGE_EIG = 2, WCT_STAGE_APPLY = 4, WCT_STAGE_ALL = 7 };
+// WCT_STAGE_EIG_FP32UPDATE (with WCT_STAGE_EIG): the eigensolver's tile updates on fp32 MFMA instead of split fp16 -- style-swap, whose
+// patch matching is an argmax over the whitened features (csrc/jacobi_dev.h r4::fused_u)
+enum { WCT_STAGE_COV = 1, WCT_STAGE_EIG = 2, WCT_STAGE_APPLY = 4, WCT_STAGE_ALL = 7, WCT_STAGE_EIG_FP32UPDATE = 8 };
 int launch_adain(const float* content, int Nc, const float* style, int Ns, int C, int P,
                  float alpha, float eps, half_t* out16, float* out32,
                  void* workspace, size_t workspace_bytes, hipStream_t s, int shared_style,

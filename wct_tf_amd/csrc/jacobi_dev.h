@@ -259,6 +259,7 @@ struct JacobiFusedArgs {
   const float* Qr; const float* Sr;   // [nmat][npair][M2*M2] rotations / rotated pair problems of step_u
   float* Qw; float* Sw;               // ... written by the D part (step_d)
   const half_t* Qr16; half_t* Qw16;   // the same rotations split into fp16 hi + lo MFMA fragments (V <- V Q; see qfrag16)
+  int u_f16 = 0;                      // tile update of the 64-wide block pairs on split fp16 (r4::fused_u) instead of fp32 MFMA
   JacobiState* st;
   int C, nmat;
   int step_d, step_u;   // outer step of the pair problems / of the tile update (= the step before step_d)
@@ -1096,7 +1097,7 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
       *reinterpret_cast<f32x4*>(Vm + (size_t)(g * M2 + 16 * ti + li) * C + pair_index<B>(16 * tj + 4 * lq, hi, hj)) = acc[tj];
     return;
   }
-#ifdef WCT_JACOBI_U_F16      // (built, measured, NOT the product: see the note at the end of this comment)
+  if (p.u_f16) {
   // Round 6: the update of an off-diagonal tile, Y = Q_g^T (X Q_h), on the fp16 MFMA pipe with split operands instead of 2 x 64
   // v_mfma_f32_16x16x4_f32 per wave -- 48 v_mfma_f32_16x16x32_f16 at a sixteenth of the cost each.  At 64 matrices the tile
   // update was the throughput-bound half of a {D, U} launch (profiles/r05_du_split.txt: 19 of 52.6 us).
@@ -1121,10 +1122,12 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
   // 33.8 KB of LDS as before, three barriers (two before).
   // RESULT (profiles/r06_tile_update_f16.txt, same box A-B): eigensolver 11.47 -> 10.83 ms per 32-pair step, 8.15 -> 7.5 at 16, 6.63
   // -> 6.37 at 8; wct_eigh to full convergence as accurate as with the fp32 update (eigenvalues 2.8e-5, whitening matrix 1.3e-5 vs
-  // 1.1e-5 of float64's), every transform test, golden and fuzz case inside its budget -- but style-swap's patch matching
-  // (an ARGMAX over correlations of whitened features) flipped 3..12 of 900 matches on the 32 x 32 test case, matches the oracle
-  // decides by up to 1.3e-3, where the fp32 update flips none; the unconditional refresh A <- V^T A0 V does not change that.  The
-  // cause was not found in the time left, so the product keeps the fp32 update (-DWCT_JACOBI_U_F16 builds this one).
+  // 1.1e-5 of float64's), every transform test, golden and fuzz case inside its budget; the WHITENING the transform applies
+  // (tools/probe/r06_whitening_accuracy.py: alpha = 1 against an identity-covariance style) is at 3.1e-4 / 3.3e-4 / 4.5e-5 of
+  // float64's where the fp32 update gives 2.8e-4 / 6.3e-5 / 4.5e-5 -- the same band, set by the residual-based stop and the
+  // second-order completion, not by the update.  Style-swap's patch matching is an ARGMAX over correlations of whitened features
+  // and flips matches the oracle decides by less than ~4 x that error; its one-pair solve therefore keeps the fp32 update
+  // (JacobiFusedArgs::u_f16 = 0: launch_style_swap and wct_eigh), the batched transform path takes this one.
   constexpr int NCH = M2 / 32;
   constexpr float LO_UP = 4096.f, LO_DOWN = 1.f / 4096.f;
   typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -1260,7 +1263,7 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
   for (int tj = 0; tj < NW; ++tj)
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[tj][r] = (acc[tj][r] + accs[tj][r] * LO_DOWN) * cdown[tj];
-#else
+  } else {
   float* Qh = jsm;                                  // [FR] the log of pair h, unit order
   float* Tt = jsm + FR;                             // [M2][P4] T transposed
   f32x4 xa[NW], ga[NW];
@@ -1308,7 +1311,7 @@ __device__ __forceinline__ void fused_u(const JacobiFusedArgs& p, int m, int tas
       for (int tj = 0; tj < NW; ++tj)
         acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[gg][sx], b4[tj][sx], acc[tj], 0, 0, 0);
   }
-#endif
+  }
   float* Pw = p.Pw + m * cc;
 #pragma unroll
   for (int tj = 0; tj < NW; ++tj) {
