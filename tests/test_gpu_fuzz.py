@@ -9,6 +9,7 @@ What the sweep is after:
   * conv3x3: any H, W >= 2, channel counts from the path, with and without the folded upsample / ReLU;
   * CORAL: arbitrary image sizes (exact integer moments)."""
 import contextlib
+import os
 
 import numpy as np
 import pytest
@@ -23,8 +24,11 @@ from wct_tf_amd import _lib  # noqa: E402
 pytestmark = pytest.mark.gpu
 # no shrinking phase: a failing example is reported as drawn (shrinking re-runs the oracle's SVDs for minutes while the GPU
 # box idles -- 5 of the 10 minutes of the round-5 lease that found the wide-band excess below)
-COMMON = dict(deadline=None, derandomize=True, suppress_health_check=list(HealthCheck),
-              phases=(Phase.explicit, Phase.reuse, Phase.generate))
+# WCT_FUZZ_SCALE=k (tools/gpu_fuzz_wide.sh): k times the examples of every sweep, drawn at RANDOM instead of derandomised -- the
+# wide runs between rounds that look for what the fixed sequence does not draw (round 6: the noise-above-the-cut-off case)
+FUZZ_SCALE = int(os.environ.get('WCT_FUZZ_SCALE', '1'))
+COMMON = dict(deadline=None, derandomize='WCT_FUZZ_SCALE' not in os.environ, suppress_health_check=list(HealthCheck),
+              phases=(Phase.explicit, Phase.reuse, Phase.generate), database=None)
 STATS = {'wct_cases': 0, 'wct_near_cutoff': 0, 'wct_indeterminate': 0, 'wct_wide': 0, 'wct_wide_worst': 0.0}
 
 
@@ -157,27 +161,50 @@ def _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     assert gpu_exact < max(1e-3, 4 * ref_noise), (c, nc, ns, alpha, mode, log_scale, gpu_exact, ref_noise)
 
 
+FAILS = []
+
+
+def _wct_case_collect(*args):
+    """the suite: the case, as it is.  Wide runs (WCT_FUZZ_SCALE): a failing case is recorded and the sweep goes on, so that one run reports
+    ALL the cases it found (test_wct_random_shapes_report fails on them)"""
+    if FUZZ_SCALE == 1:
+        return _wct_case(*args)
+    try:
+        _wct_case(*args)
+    except AssertionError as e:
+        FAILS.append((args[1:], str(e).splitlines()[0][:200]))
+        print('FUZZ-FAIL %r: %s' % FAILS[-1])
+
+
 # (found by a run of this sweep in round 6 -- the generator's sequence depends on the tests that ran before it in the process -- and
 # kept as an explicit case: N << C at the top of the scale range, rounding noise of the covariance five decades above the cut-off)
 @example(c=256, hc=12, wc=7, hs=13, ws=6, alpha=0.23694110562368303, mode='np', log_scale=3.0, seed=464496)
 @example(c=256, hc=12, wc=7, hs=13, ws=6, alpha=0.9, mode='tf', log_scale=3.0, seed=4)
-@settings(max_examples=30, **COMMON)
+# (found by the first wide run, tools/gpu_fuzz_wide.sh 8 -- 289 cases, these four over the bound, in the round-5 library as well:
+#  a graded spectrum whose worst row the MEAN residual hid (1.35e-3; the stop test now bounds the worst row too), and clusters of
+#  eigenvalues a few per cent apart around the cut-off (1.1e-3 .. 1.4e-2; the residual across the cut-off is now measured against
+#  the GAP) -- profiles/r06_fuzz_wide.txt)
+@example(c=64, hc=12, wc=6, hs=20, ws=10, alpha=0.959527218831276, mode='tf', log_scale=1.2633897218325192, seed=5076692)
+@example(c=128, hc=12, wc=25, hs=25, ws=23, alpha=0.8727483594839052, mode='np', log_scale=-1.8471459453454355, seed=38)
+@example(c=256, hc=8, wc=19, hs=9, ws=17, alpha=0.8948437019837017, mode='np', log_scale=-1.7328125291679197, seed=176)
+@settings(max_examples=30 * FUZZ_SCALE, **COMMON)
 @given(c=st.sampled_from([32, 64, 96, 128, 160, 256]), hc=st.integers(2, 26), wc=st.integers(2, 26),
        hs=st.integers(2, 26), ws=st.integers(2, 26),
        alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['np', 'tf']), log_scale=st.floats(-3.0, 3.0),
        seed=st.integers(0, 2 ** 31 - 1))
 def test_wct_random_shapes_and_scales(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed):
-    _wct_case(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed)
+    _wct_case_collect(ctx, c, hc, wc, hs, ws, alpha, mode, log_scale, seed)
 
 
-@settings(max_examples=6, **COMMON)
+@example(hc=14, wc=31, hs=12, ws=29, alpha=0.9304784057570625, mode='tf', log_scale=-1.0695702389412896, seed=501)
+@settings(max_examples=6 * FUZZ_SCALE, **COMMON)
 @given(hc=st.integers(2, 40), wc=st.integers(2, 40), hs=st.integers(2, 40), ws=st.integers(2, 40),
        alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['np', 'tf']), log_scale=st.floats(-3.0, 3.0),
        seed=st.integers(0, 2 ** 31 - 1))
 def test_wct_random_shapes_and_scales_512_channels(ctx, hc, wc, hs, ws, alpha, mode, log_scale, seed):
     """the same sweep at C = 512, the channel count of two of the five levels (relu4_1, relu5_1): pixel counts from 4 to
     1600 on either side of C, so full-rank and rank-deficient covariances both occur"""
-    _wct_case(ctx, 512, hc, wc, hs, ws, alpha, mode, log_scale, seed)
+    _wct_case_collect(ctx, 512, hc, wc, hs, ws, alpha, mode, log_scale, seed)
 
 
 
@@ -189,9 +216,10 @@ def test_wct_random_shapes_report():
           '%(wct_indeterminate)d of those with a reference output that is itself rounding noise above 2.5e-4, %(wct_wide)d with a band '
           'of eight or more noise eigenvalues (judged against the float64 outcomes: worst %(wct_wide_worst).2e)' % STATS)
     assert STATS['wct_cases'] >= 36
+    assert not FAILS, FAILS
 
 
-@settings(max_examples=15, **COMMON)
+@settings(max_examples=15 * FUZZ_SCALE, **COMMON)
 @given(c=st.sampled_from([4, 32, 64, 128, 512]), hc=st.integers(2, 30), wc=st.integers(2, 30),
        hs=st.integers(2, 30), ws=st.integers(2, 30),
        alpha=st.floats(0.0, 1.0), log_scale=st.floats(-2.0, 2.0), seed=st.integers(0, 2 ** 31 - 1))
@@ -204,7 +232,7 @@ def test_adain_random_shapes(ctx, c, hc, wc, hs, ws, alpha, log_scale, seed):
     assert rel_err(got, want) < 1e-4 and max_rel(got, want) < 1e-3
 
 
-@settings(max_examples=25, **COMMON)
+@settings(max_examples=25 * FUZZ_SCALE, **COMMON)
 @given(h=st.integers(2, 70), w=st.integers(2, 70), cin=st.sampled_from([64, 128, 256]),
        cout=st.sampled_from([64, 128, 256]), relu=st.booleans(), up=st.booleans(), seed=st.integers(0, 2 ** 31 - 1))
 def test_conv3x3_random_shapes(ctx, h, w, cin, cout, relu, up, seed):
@@ -220,7 +248,7 @@ def test_conv3x3_random_shapes(ctx, h, w, cin, cout, relu, up, seed):
     assert rel_err(got, want) < 2e-4 and max_rel(got, want) < 1e-3, (h, w, cin, cout, relu, up)
 
 
-@settings(max_examples=12, **COMMON)
+@settings(max_examples=12 * FUZZ_SCALE, **COMMON)
 @given(hs=st.integers(1, 90), ws=st.integers(1, 90), ht=st.integers(1, 90), wt=st.integers(1, 90),
        seed=st.integers(0, 2 ** 31 - 1))
 def test_coral_random_sizes(ctx, hs, ws, ht, wt, seed):
@@ -236,7 +264,7 @@ def test_coral_random_sizes(ctx, hs, ws, ht, wt, seed):
     assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
 
 
-@settings(max_examples=12, **COMMON)
+@settings(max_examples=12 * FUZZ_SCALE, **COMMON)
 @given(hc=st.integers(16, 90), wc=st.integers(16, 90), hs=st.integers(16, 90), ws=st.integers(16, 90),
        levels=st.lists(st.sampled_from([5, 4, 3, 2, 1]), min_size=1, max_size=4, unique=True),
        alpha=st.floats(0.0, 1.0), mode=st.sampled_from(['tf', 'np']), adain=st.booleans(), seed=st.integers(0, 1000))

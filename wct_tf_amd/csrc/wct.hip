@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(256) void jacobi_gather_kernel(float* A, const floa
 }
 
 // mat0 = index of the group's first matrix in the 2P batch; skipped style matrices start out `done`
-__global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float* V, JacobiState* st, int C, int mat0, int shared_style) {
+__global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float* V, JacobiState* st, int C, int mat0, int shared_style, unsigned* rowsum) {
   __shared__ float red[4];
   const int m = blockIdx.y;
   const bool skip = skip_style_mat(mat0 + m, shared_style);
@@ -1268,6 +1268,7 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x)
       V[(size_t)m * cc + i] = (i / C == i % C) ? 1.f : 0.f;
   if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < C; i += 256) rowsum[(size_t)m * 1024 + i] = 0u;      // (JACOBI_ROWSUM_MAX words per matrix: jacobi_resid_kernel)
     float mx = 0.f;                          // NaN diagonals drop out of fmaxf; the pair kernels flag them
     if (!skip) for (int i = threadIdx.x; i < C; i += 256) mx = fmaxf(mx, fabsf(A[(size_t)m * cc + (size_t)i * C + i]));
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1312,10 +1313,21 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
 constexpr int JACOBI_RESID_T = 64;
 constexpr int JACOBI_RESID_MAXTILES = 136;             // C <= 1024: 16 x 17 / 2
 constexpr int JACOBI_RESID_STRIDE = 8;                 // floats per (matrix, tile)
+// Round 6: the stop test also bounds the WORST ROW.  r2 is a mean over the rows of a row's sum of squared cosines; the completion's
+// error in ONE eigen-direction is set by that direction's own row, and a mean over C rows hides a row C times above it -- graded
+// spectra do that (the rows of the smallest eigenvalues settle last): C = 64, 72 pixels, eigenvalues 4.5e3 .. 3.5e-2 stopped at
+// sweep 5 with the mean under the threshold and the transform 1.35e-3 off; one sweep later 4e-6 (wide fuzz run,
+// profiles/r06_fuzz_wide.txt).  Row sums: every tile adds its 64 row and 64 column sums into rowsum[m][C] as 2^-20 fixed point
+// with integer atomics (associative: the sums, and with them the sweep counts and every output bit, do not depend on the order),
+// jacobi_check_kernel takes the maximum, clears the words, and a matrix is done only if max_p rowsum_p / 2 < JACOBI_ROW_K tol^2 too.
+constexpr int JACOBI_ROWSUM_MAX = 1024;                // words per matrix (C <= 1024)
+constexpr float JACOBI_ROW_K = 8.f;
+constexpr float JACOBI_ROW_FIX = 1048576.f;            // 2^20
 struct JacobiCheckArgs {
   int mid;                   // 1: the test in the middle of a sweep (jacobi_check_mid)
   float tol_max, tol_fn;
   int buf, segs, lenient_from;
+  float row_k;               // JACOBI_ROW_K (tuning builds: WCT_JACOBI_ROW_K)
 };
 
 // done: 0 = still rotating, 1 = converged, 2 = failed (a non-finite element reached a pair problem).
@@ -1325,14 +1337,15 @@ struct JacobiCheckArgs {
 // lenient_from: from this many completed sweeps on, a matrix whose SIGNIFICANT pairs were all below tol_max in the sweep
 // is done as well (what jacobi_finalize_kernel accepts when the budget runs out): the noise-level pairs of a
 // rank-deficient matrix never settle, and without this such a matrix always burns the whole sweep budget.
-__device__ __forceinline__ void jacobi_check_end(JacobiState& s, const float (&v)[4], const JacobiCheckArgs& a) {
+__device__ __forceinline__ void jacobi_check_end(JacobiState& s, const float (&v)[5], const JacobiCheckArgs& a) {
   s.sweeps += 1;
   const float r2 = v[0] / fmaxf(v[1], 1.f);
+  const bool rows_ok = v[4] < a.row_k * a.tol_fn * a.tol_fn;
   s.r2 = r2;
   s.r2l = v[2] / fmaxf(v[3], 1.f);
   const unsigned bits = s.offmax;                       // max of non-negative floats as bit patterns; >= 0x7f800000: inf / NaN
   if (bits >= 0x7f800000u || !(r2 < 3.0e38f)) s.done = 2;
-  else if (__uint_as_float(bits) < a.tol_max || (a.tol_fn > 0.f && r2 < a.tol_fn * a.tol_fn)) s.done = 1;
+  else if (__uint_as_float(bits) < a.tol_max || (a.tol_fn > 0.f && r2 < a.tol_fn * a.tol_fn && rows_ok)) s.done = 1;
   else if (s.sweeps >= a.lenient_from && __uint_as_float(s.offsig) < a.tol_max) s.done = 1;
   if (s.done) { s.pad = a.buf; s.seg_stop = a.segs; }
   s.last_sig = s.offsig;
@@ -1345,9 +1358,9 @@ __device__ __forceinline__ void jacobi_check_end(JacobiState& s, const float (&v
 // of a sweep (tools/jacobi_block_order_proto.py), so a matrix that a full sweep would take 10x below the stop threshold
 // is usually below it half a sweep earlier; its remaining launches of the sweep turn into no-ops.  Touches nothing but
 // `done`, r2 / r2l and the sweep count (the half sweep counts as one).
-__device__ __forceinline__ void jacobi_check_mid(JacobiState& s, const float (&v)[4], const JacobiCheckArgs& a) {
+__device__ __forceinline__ void jacobi_check_mid(JacobiState& s, const float (&v)[5], const JacobiCheckArgs& a) {
   const float r2 = v[0] / fmaxf(v[1], 1.f);
-  if (s.offmax < 0x7f800000u && r2 < a.tol_fn * a.tol_fn) {       // finite so far and converged
+  if (s.offmax < 0x7f800000u && r2 < a.tol_fn * a.tol_fn && v[4] < a.row_k * a.tol_fn * a.tol_fn) {       // finite so far and converged
     s.r2 = r2;
     s.r2l = v[2] / fmaxf(v[3], 1.f);
     s.last_sig = s.offsig;
@@ -1359,10 +1372,11 @@ __device__ __forceinline__ void jacobi_check_mid(JacobiState& s, const float (&v
 }
 
 // grid (tiles of the upper triangle, matrices)
-__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const JacobiState* st, float* partial, int C) {
+__global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const JacobiState* st, float* partial, int C, unsigned* rowsum, float mixed_w) {
   constexpr int T = JACOBI_RESID_T;
   __shared__ float dr[T], dc[T], ir[T], ic[T];
   __shared__ float red[5][4];
+  __shared__ float colred[4][T];
   const int m = blockIdx.y, tid = threadIdx.x;
   if (st[m].done) return;                                // (jacobi_check_kernel skips the matrix as well)
   const int ntr = (C + T - 1) / T;
@@ -1393,6 +1407,7 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
   // an ordered pair (p, q) weighs 1/2: an off-diagonal tile stands for its mirror image too
   const float w = diag ? 0.5f : 1.f;
   const int c4 = (tid & 15) * 4, gq = tj * T + c4;
+  float sr[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};     // this thread's part of its 4 rows' / 4 columns' strict sums
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = (tid >> 4) + 16 * k, gp = ti * T + r;
@@ -1409,19 +1424,50 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
         const float e2 = (diag && r == c4 + j) ? 0.f : w * e4[j] * e4[j];
         const float cos2 = e2 * ip * iq;
         const float mixed = e2 * ibig * (ibig + (small < 1e-5f ? 0.01f * 1e5f : 0.f));
+        // Round 6: ACROSS the cut-off f jumps, and what the residual does there is rotate the kept direction into the dropped one by
+        // e / (d_k - d_d), not e / d_k: with a cluster of eigenvalues around 1e-5 (spacing of a few per cent: 8 of a 128-channel
+        // covariance within +-20 % in the wide fuzz run, profiles/r06_fuzz_wide.txt) the old measure let the sweeps stop at angles of
+        // 0.2 .. 0.4 between neighbours on either side, 1.1e-3 .. 1.4e-2 of the transform.  The gap is floored at 1e-3 of the larger
+        // diagonal (closer pairs float32 cannot tell apart: either side is the reference's).
+        const float big = bigp ? dp : dq;
+        const float igap = __builtin_amdgcn_rcpf(fmaxf(big - small, 1e-3f * big));
+        const float across = e2 * (igap * igap + ibig * (small < 1e-5f ? 0.01f * 1e5f : 0.f));
         v[0] += (kp & kq) ? cos2 : 0.f;
-        v[1] += (kp ^ kq) ? mixed : 0.f;
+        v[1] += (kp ^ kq) ? across : 0.f;
+        const float se = (kp & kq) ? cos2 : ((kp ^ kq) ? mixed_w * across : 0.f);
+        sr[k] += se;
+        sc[j] += se;
         v[3] += (sp & sq) ? cos2 : ((sp | sq) ? mixed : 0.f);
       }
     }
   }
   const int near_any = __syncthreads_or(near);
+  // row sums: the 16 lanes of a row group hold a row's 64 columns; column sums: 4 rows per thread, 4 row groups per wave, 4 waves.
+  // (a diagonal tile weighs an ordered pair 1/2 and holds both orders: its row and column sums add up to the whole)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float x = sr[k];
+    for (int o = 1; o < 16; o <<= 1) x += __shfl_xor(x, o, 64);
+    const int gp = ti * T + (tid >> 4) + 16 * k;
+    if ((tid & 15) == 0 && gp < C) atomicAdd(rowsum + (size_t)m * JACOBI_ROWSUM_MAX + gp, (unsigned)(fminf(x, 32.f) * JACOBI_ROW_FIX + 0.5f));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = sc[j];
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    if ((tid & 63) < 16) colred[tid >> 6][c4 + j] = x;
+  }
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_xor(v[j], o, 64);
     if ((tid & 63) == 0) red[j][tid >> 6] = v[j];
   }
   __syncthreads();
+  if (tid < T && tj * T + tid < C) {
+    const float x = (colred[0][tid] + colred[1][tid]) + (colred[2][tid] + colred[3][tid]);
+    atomicAdd(rowsum + (size_t)m * JACOBI_ROWSUM_MAX + tj * T + tid, (unsigned)(fminf(x, 32.f) * JACOBI_ROW_FIX + 0.5f));
+  }
   float* out = partial + ((size_t)m * JACOBI_RESID_MAXTILES + blockIdx.x) * JACOBI_RESID_STRIDE;
   if (tid < 5) out[tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
   if (tid == 5) out[5] = near_any ? 1.f : 0.f;
@@ -1429,9 +1475,16 @@ __global__ __launch_bounds__(256) void jacobi_resid_kernel(const float* A, const
 
 // grid (matrices), one wave: the measurement's sums over the tiles, then the test (ck.mid: the one in the middle of a sweep)
 __global__ __launch_bounds__(64) void jacobi_check_kernel(JacobiState* st, const float* partial, int ntile, float mixed_w, JacobiCheckArgs ck,
-                                                          int* done_host /* this group's mapped host words, or null */) {
+                                                          int* done_host /* this group's mapped host words, or null */, unsigned* rowsum, int C) {
   const int m = blockIdx.x, tid = threadIdx.x;
   if (st[m].done) { if (tid == 0 && done_host) done_host[m] = st[m].done; return; }
+  unsigned rmax = 0u;                                   // the worst row's sum (fixed point), and the words cleared for the next measurement
+  for (int p = tid; p < C; p += 64) {
+    unsigned* w = rowsum + (size_t)m * JACOBI_ROWSUM_MAX + p;
+    rmax = max(rmax, *w);
+    *w = 0u;
+  }
+  for (int o = 32; o > 0; o >>= 1) rmax = max(rmax, (unsigned)__shfl_xor((int)rmax, o, 64));
   float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* pm = partial + (size_t)m * JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE;
   for (int tt = tid; tt < ntile; tt += 64)
@@ -1444,7 +1497,7 @@ __global__ __launch_bounds__(64) void jacobi_check_kernel(JacobiState* st, const
     const bool near_m = a[5] > 0.f;
     // remembered for jacobi_finalize_kernel: such a matrix has only the first-order completion to pay for a late acceptance
     st[m].pad2 = near_m ? 1 : 0;
-    const float vv[4] = {(near_m ? mixed_w : 1.f) * a[0] + mixed_w * a[1], a[2], a[3], a[4]};
+    const float vv[5] = {(near_m ? mixed_w : 1.f) * a[0] + mixed_w * a[1], a[2], a[3], a[4], 0.5f * (float)rmax * (1.f / JACOBI_ROW_FIX)};
     if (ck.mid) jacobi_check_mid(st[m], vv, ck); else jacobi_check_end(st[m], vv, ck);
     if (done_host) done_host[m] = st[m].done;
   }
@@ -1508,7 +1561,7 @@ size_t jacobi_workspace_bytes(int C, int nmat) {
   // widths) and the same again as fp16 hi/lo fragments, two generations of rotated pair problems (2 x C x M2 <= 128 C), the second matrix buffer (C^2); then state
   // words and residual partials
   return (size_t)nmat * ((size_t)9 * C * C + (size_t)128 * C) * sizeof(float) + 1024 +
-         (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE * sizeof(float));
+         (size_t)nmat * (sizeof(JacobiState) + JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE * sizeof(float) + JACOBI_ROWSUM_MAX * sizeof(unsigned));
 }
 
 // One group = a set of matrices on its own stream (the two halves of a batch run as two groups so
@@ -1730,12 +1783,19 @@ static void jacobi_enqueue_segment(JacobiGroup* grp, int ngrp, int C, int step_b
       jacobi_fused_launch<M2>(grp[g], C, step_begin, step < step_end, step, step > step_begin, step - 1, step == step_begin);
 }
 
+static float jacobi_row_k() {
+  static const float k = tune_float("WCT_JACOBI_ROW_K", JACOBI_ROW_K);
+  return k;
+}
+
 // residual measurement of the group's matrices (in P[cur]), then the test `ck`
 static void jacobi_measure(JacobiGroup& G, int C, const JacobiCheckArgs& ck) {
   const int ntr = (C + JACOBI_RESID_T - 1) / JACOBI_RESID_T;
   const int ntile = ntr * (ntr + 1) / 2;
-  hipLaunchKernelGGL(jacobi_resid_kernel, dim3(ntile, G.nmat), dim3(256), 0, G.stream, G.P[G.cur], G.st, G.resid, C);
-  hipLaunchKernelGGL(jacobi_check_kernel, dim3(G.nmat), dim3(64), 0, G.stream, G.st, G.resid, ntile, G.tol_fn > 2e-2f ? 7.1f : 1.f, ck, G.done_host);
+  const float mixed_w = G.tol_fn > 2e-2f ? 7.1f : 1.f;
+  unsigned* rowsum = reinterpret_cast<unsigned*>(G.resid + (size_t)G.nmat * JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE);
+  hipLaunchKernelGGL(jacobi_resid_kernel, dim3(ntile, G.nmat), dim3(256), 0, G.stream, G.P[G.cur], G.st, G.resid, C, rowsum, mixed_w);
+  hipLaunchKernelGGL(jacobi_check_kernel, dim3(G.nmat), dim3(64), 0, G.stream, G.st, G.resid, ntile, mixed_w, ck, G.done_host, rowsum, C);
   LAUNCH_NOTE("jacobi_resid_kernel / jacobi_check_kernel");
 }
 
@@ -1758,7 +1818,8 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     G.vstrip = host && g < 4 && vstrip_supported<M2>(C) && (vs_env == 2 || (vs_env == 1 && G.nmat >= vs_min && C >= 256));
     if (G.vstrip) { G.vs = host->vs[g]; G.ev_seg = host->ev_seg[g]; G.ev_v[0] = host->ev_v[g][0]; G.ev_v[1] = host->ev_v[g][1]; }
     G.done_host = host && g < 4 ? host->flags_dev + g * 64 : nullptr;
-    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, G.nmat), dim3(256), 0, G.stream, G.A, G.V, G.st, C, G.mat0, G.shared_style);
+    hipLaunchKernelGGL(jacobi_init_kernel, dim3(64, G.nmat), dim3(256), 0, G.stream, G.A, G.V, G.st, C, G.mat0, G.shared_style,
+                       reinterpret_cast<unsigned*>(G.resid + (size_t)G.nmat * JACOBI_RESID_MAXTILES * JACOBI_RESID_STRIDE));
     HIP_TRY(hipGetLastError());
   }
   bool pending = false;
@@ -1786,14 +1847,14 @@ static int jacobi_run_groups_fused(JacobiGroup* grp, int ngrp, int C) {
     if (mid) {
       for (int g = 0; g < ngrp; ++g)
         if (grp[g].tol_fn > 0.f) {
-          jacobi_measure(grp[g], C, JacobiCheckArgs{1, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, 1 << 30});
+          jacobi_measure(grp[g], C, JacobiCheckArgs{1, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, 1 << 30, jacobi_row_k()});
         }
       if ((rc = jacobi_segment_begin(grp, ngrp))) return rc;
       jacobi_enqueue_segment<M2>(grp, ngrp, C, half, nblk - 1, half, nblk);
       if ((rc = jacobi_segment_end<M2>(grp, ngrp, C, half, nblk - 1))) return rc;
     }
     for (int g = 0; g < ngrp; ++g) {
-      jacobi_measure(grp[g], C, JacobiCheckArgs{0, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, max_sweeps - 3});
+      jacobi_measure(grp[g], C, JacobiCheckArgs{0, conv_tol, grp[g].tol_fn, grp[g].cur, grp[g].segs, max_sweeps - 3, jacobi_row_k()});
     }
     if (host && sweep >= 2 && sweep + 1 < max_sweeps) {
       for (int g = 0; g < ngrp; ++g) {
