@@ -822,12 +822,20 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     floor_m = p.st[m].floor;
     JTS(1);
     const float* Am = p.Pr + (size_t)m * C * C;
-    for (int e = tid; e < FR; e += NT) {
-      const int r = e / M2, c = e % M2;
-      const float v = Am[(size_t)pair_index<B>(r, bi, bj) * C + pair_index<B>(c, bi, bj)];
-      finite &= fabsf(v) <= 3.0e38f;
-      if (r == c) my_dm = fmaxf(my_dm, fabsf(v));
-      Simg[r * SP + c] = v;
+    {
+      // (round 6: 16-byte pieces -- four consecutive columns lie in one block of the pair; 4 loads per lane where 16 scalar ones,
+      //  each with its own index arithmetic, stood)
+      const int r0 = tid >> 4, c4 = (tid & 15) * 4;
+      const float* col = Am + pair_index<B>(c4, bi, bj);
+#pragma unroll
+      for (int i = 0; i < FR / 4 / NT; ++i) {
+        const int r = r0 + (NT / 16) * i;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(col + (size_t)pair_index<B>(r, bi, bj) * C);
+        finite &= (fabsf(v[0]) <= 3.0e38f) & (fabsf(v[1]) <= 3.0e38f) & (fabsf(v[2]) <= 3.0e38f) & (fabsf(v[3]) <= 3.0e38f);
+        const int dd = r - c4;
+        if (dd >= 0 && dd < 4) my_dm = fmaxf(my_dm, fabsf(dd == 0 ? v[0] : (dd == 1 ? v[1] : (dd == 2 ? v[2] : v[3]))));
+        *reinterpret_cast<f32x4*>(Simg + r * SP + c4) = v;
+      }
     }
     if (p.step_d < 0)                              // intra step: the Q image starts as zero (its diagonal blocks are written after the sets)
       for (int e = tid; e < SIMG_F; e += NT) jsm[SIMG_F + e] = 0.f;
@@ -841,15 +849,21 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
     const float* S1 = p.Sr + ((size_t)m * npair + g1) * FR;
     const float* S2 = p.Sr + ((size_t)m * npair + g2) * FR;
     const bool same = g1 == g2;
-    float sv[FR / NT];
+    // (round 6: 16-byte pieces.  A lane holds columns c4 .. c4 + 3 of the rows r0 + (NT / 16) i: which HALF the row lies in is a
+    //  compile-time property of i, the column half one of the lane -- 4 loads and a handful of address instructions per lane where
+    //  16 scalar loads, each with its own selects, stood: the launch's first wait came after 620 instructions)
+    constexpr int RP = NT / 16, NV4 = FR / 4 / NT;
+    static_assert(B % RP == 0, "a pass of rows lies in one half of the pair problem");
+    const int r0 = tid >> 4, c4 = (tid & 15) * 4;
+    const bool clo = c4 < B;
+    const int ccol = (clo ? h1 : h2) * B + (c4 & (B - 1));
+    f32x4 sv[NV4];
 #pragma unroll
-    for (int i = 0; i < FR / NT; ++i) {
-      const int e = tid + i * NT, r = e / M2, c = e % M2;
-      const bool rlo = r < B, clo = c < B;
-      const float* src = rlo ? S1 : S2;
-      const int rr = (rlo ? h1 : h2) * B + (rlo ? r : r - B);
-      const int cc = (clo ? h1 : h2) * B + (clo ? c : c - B);
-      sv[i] = (rlo == clo || same) ? src[rr * M2 + cc] : 0.f;
+    for (int i = 0; i < NV4; ++i) {
+      const bool rlo = RP * i < B;
+      const int rr = (rlo ? h1 : h2) * B + ((r0 + RP * i) & (B - 1));
+      sv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rlo == clo || same) sv[i] = *reinterpret_cast<const f32x4*>((rlo ? S1 : S2) + rr * M2 + ccol);
     }
     // W = Q_g1[:, h1]^T X (B x M2: 8 MFMA tiles over the waves, the jobs of a wave share their tile row), then crit = W
     // Q_g2[:, h2] (B x B: one tile per wave 0..3).  Operands as in fused_u: k-slot 16 g + 4 lq + s, so the rotation matrices come
@@ -912,12 +926,14 @@ __device__ __forceinline__ void fused_d(const JacobiFusedArgs& p, int m, int g, 
       JTS(3);
     }
 #pragma unroll
-    for (int i = 0; i < FR / NT; ++i) {
-      const int e = tid + i * NT, r = e / M2, c = e % M2;
-      if ((r < B) == (c < B) || same) {
-        Simg[r * SP + c] = sv[i];
-        finite &= fabsf(sv[i]) <= 3.0e38f;
-        if (r == c) my_dm = fmaxf(my_dm, fabsf(sv[i]));
+    for (int i = 0; i < NV4; ++i) {
+      const int r = r0 + RP * i;
+      if ((RP * i < B) == clo || same) {
+        const f32x4 v = sv[i];
+        *reinterpret_cast<f32x4*>(Simg + r * SP + c4) = v;
+        finite &= (fabsf(v[0]) <= 3.0e38f) & (fabsf(v[1]) <= 3.0e38f) & (fabsf(v[2]) <= 3.0e38f) & (fabsf(v[3]) <= 3.0e38f);
+        const int dd = r - c4;
+        if (dd >= 0 && dd < 4) my_dm = fmaxf(my_dm, fabsf(dd == 0 ? v[0] : (dd == 1 ? v[1] : (dd == 2 ? v[2] : v[3]))));
       }
     }
     if (!same && wave < (B / 16) * (B / 16)) {
