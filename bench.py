@@ -522,10 +522,13 @@ def main():
                 'matrices_per_step': 2 * 5 * n_local,
                 'sweeps': {str(c): {'mean': v['sweeps'] / max(1, v['matrices']), 'max': v['max_sweeps'], 'budget': 16} for c, v in sorted(eig.items())},
                 'achieved_tflops': jtf, 'peak_tflops': F32_MFMA_PEAK_TFLOPS, 'frac_of_f32_mfma_peak': jtf / F32_MFMA_PEAK_TFLOPS,
-                'flops_note': 'fp32-MFMA FLOPs of the tile updates the sweeps executed (two-sided A tiles + V Q), from the sweep '
-                              'counts the library reports (wct_eig_stats); the rotation sets themselves run on the VALU/LDS',
+                'flops_note': 'ALGORITHMIC fp32 FLOPs of the tile updates the sweeps executed (two-sided A tiles + V Q), from the sweep '
+                              'counts the library reports (wct_eig_stats); the rotation sets themselves run on the VALU/LDS.  Since round 6 the '
+                              'A-tile updates of this (batched transform) path run as split-fp16 products on the fp16 MFMA pipe (48 '
+                              'v_mfma_f32_16x16x32_f16 per wave and tile where 128 v_mfma_f32_16x16x4_f32 stood), like V Q since round 4: the '
+                              'fp32-MFMA peak is kept as the yardstick for comparison with the earlier rounds',
                 'bound': 'VALU issue of the rotation sets (one wave per SIMD and pair problem; the chain of a set runs through the '
-                         'pivot wave) + fp32-MFMA tile updates',
+                         'pivot wave) + the tile updates (split-fp16 MFMA)',
                 'note': 'batched two-sided block Jacobi on the %d-level covariances (C = 512, 512, 256, 128, 64; content and style); '
                         'look-ahead launches {pair problems of step s, tile update of step s-1}; from 256 channels on the 64 x 64 pair '
                         'problems are resident in REGISTERS (256 threads, 1 x W strips of cells, rim exchange through LDS, scaled '
