@@ -248,6 +248,35 @@ def test_conv3x3_random_shapes(ctx, h, w, cin, cout, relu, up, seed):
     assert rel_err(got, want) < 2e-4 and max_rel(got, want) < 1e-3, (h, w, cin, cout, relu, up)
 
 
+@settings(max_examples=16 * FUZZ_SCALE, **COMMON)
+@given(h=st.integers(2, 44), w=st.integers(2, 44), cin=st.sampled_from([256, 512]), cout=st.sampled_from([256, 512]),
+       relu=st.booleans(), up=st.booleans(), pool=st.booleans(), batch=st.integers(1, 3), seed=st.integers(0, 2 ** 31 - 1))
+def test_conv3x3_reduced_flop_kernel_random_shapes(ctx, h, w, cin, cout, relu, up, pool, batch, seed):
+    """csrc/conv_wino.hip (round 6: Winograd F(2,3) along y, direct along x) through wct_conv3x3_f16 with the kernel forced, on
+    sizes the pipeline's layers do not enumerate -- down to 2 x 2 (every row a reflected edge), odd heights (a pair-row with one row
+    inside), batches, the folded upsample and the fused ceil-mode pool: against the restatement with its own roundings (1e-4;
+    one fp16 ulp on an element), the fp32 oracle (the 1.5e-3 gate of the layer), and the batch must not matter."""
+    if pool and not relu:
+        return                                    # (the pipeline pools only behind a ReLU; the entry point refuses the combination)
+    rng = np.random.default_rng(seed)
+    x = np.maximum(rng.standard_normal((batch, h, w, cin)), 0).astype(np.float32)
+    wt = (rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    b = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    got = ctx.conv3x3_f16(x, wt, b, relu=relu, upsample=up, pool=pool, algo=2)
+    h16 = lambda a: np.asarray(a, np.float16).astype(np.float32)   # noqa: E731
+    for i in range(batch):
+        xin = oracle.upsample2x_nearest(x[i]) if up else x[i]
+        emu = oracle.conv3x3_reflect_wino_f16(xin, wt, b, relu)
+        want32 = oracle.conv3x3_reflect(h16(xin), wt, b, relu)
+        if pool:
+            emu, want32 = oracle.maxpool2x2_same(emu), oracle.maxpool2x2_same(want32)
+        assert got[i].shape == want32.shape, (h, w, cin, cout, relu, up, pool, batch)
+        assert rel_err(got[i], emu) < 1e-4 and max_rel(got[i], emu) < 2e-3, (h, w, cin, cout, relu, up, pool, batch, i)
+        assert rel_err(got[i], want32) < 1.5e-3, (h, w, cin, cout, relu, up, pool, batch, i)
+    if batch > 1:
+        assert np.array_equal(got[0], ctx.conv3x3_f16(x[0], wt, b, relu=relu, upsample=up, pool=pool, algo=2))
+
+
 @settings(max_examples=12 * FUZZ_SCALE, **COMMON)
 @given(hs=st.integers(1, 90), ws=st.integers(1, 90), ht=st.integers(1, 90), wt=st.integers(1, 90),
        seed=st.integers(0, 2 ** 31 - 1))
