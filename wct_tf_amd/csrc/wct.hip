@@ -1170,7 +1170,9 @@ __global__ __launch_bounds__(W * 64) void jacobi_vstrip_kernel(VStripArgs p) {
   // out[mt] = sum over chunks of the three split-operand MFMAs.  The strip must stay in registers.
 #define VSTRIP_PAIR(pa, pb, g)                                                                                       \
   {                                                                                                                  \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((VS_RING - 2) * NDMA) : "memory");   /* this wave's pieces of tile q have landed */ \
+    /* this wave's pieces of tile q have landed; lgkmcnt(0): its ds_reads of tile q - 1 have RETIRED before the barrier behind which    \
+       another wave refills that slot (the fragments were consumed by the previous pair's MFMAs, the wait is free) */       \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((VS_RING - 2) * NDMA) : "memory");                           \
     __builtin_amdgcn_s_barrier();                          /* ... everybody's; and nobody reads tile q - 1 any more */ \
     asm volatile("" ::: "memory");                                                                                   \
     dma(q + VS_RING - 1);                                                                                            \
@@ -2607,7 +2609,22 @@ static int launch_refresh(const WctCarve& w, int C, int P, int shared_style, hip
   r2.A = w.V; r2.lda = C; r2.a_kmajor = 1; r2.B = w.X; r2.ldb = C; r2.b_kmajor = 1; r2.sA = r2.sB = cc; r2.skip_shared = shared_style;
   r2.M = C; r2.N = C; r2.K = C; r2.ksplit = C; r2.out32 = w.A; r2.ldo = C; r2.s_out = cc;
   if (!always) r2.mask_in = w.refresh;
-  return launch_gemm(r2, 1, 2 * P, s);
+  rc = launch_gemm(r2, 1, 2 * P, s);
+#ifdef WCT_TUNING
+  // WCT_REFRESH_STATS=1 (tuning builds): how often the predicate fires -- the flags are read back after every call (a stream
+  // sync: measurement only) and the running totals printed, per channel count
+  if (!rc && !always && tune_set("WCT_REFRESH_STATS")) {
+    static long fired[5] = {0, 0, 0, 0, 0}, seen[5] = {0, 0, 0, 0, 0};
+    int flags[64];
+    if (hipMemcpyAsync(flags, w.refresh, (size_t)2 * P * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) {
+      const int cls = C >= 512 ? 4 : (C >= 256 ? 3 : (C >= 128 ? 2 : (C >= 64 ? 1 : 0)));
+      for (int m = 0; m < 2 * P; ++m) if (!skip_style_mat(m, shared_style)) { seen[cls] += 1; fired[cls] += flags[m] != 0; }
+      fprintf(stderr, "refresh fired (running totals) C<=32 %ld/%ld | 64 %ld/%ld | 128 %ld/%ld | 256 %ld/%ld | 512+ %ld/%ld\n",
+              fired[0], seen[0], fired[1], seen[1], fired[2], seen[2], fired[3], seen[3], fired[4], seen[4]);
+    }
+  }
+#endif
+  return rc;
 }
 
 int launch_wct(const float* content, int Nc, const float* style, int Ns, int C, int P, float alpha, int mode, float eps_in,
