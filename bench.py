@@ -501,6 +501,9 @@ def main():
                     'achieved': allc, 'frac': allc / MFMA_F16_DENSE_PEAK_TFLOPS, 'launches': conv['launches'] + cw['launches'],
                     'ms_per_step': (conv['ms'] + cw['ms']) / args.steps,
                     'note': 'the 61 launches per frame set that were ONE class up to round 5 (direct-convolution FLOPs / time): compare with roofline.frac of the earlier rounds'}
+                # (roofline.frac above is the DIRECT kernel's class alone: since round 6 it has lost its most efficient layers to the
+                #  reduced-FLOP kernel, so it reads lower than round 5's 0.471 although no layer got slower; this is the like-for-like figure)
+                line['roofline']['frac_over_the_round5_class'] = allc / MFMA_F16_DENSE_PEAK_TFLOPS
             c12 = prof.get('conv12')
             if c12 and c12['ms'] > 0:
                 a12 = c12['flops'] / (c12['ms'] * 1e-3) / 1e12

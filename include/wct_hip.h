@@ -84,7 +84,12 @@ int wct_set_decoder(wct_ctx* ctx, int level, const float* const* w, const float*
 /* ---- op level (host pointers), for parity tests -------------------------------- */
 /* wct_np / wct_tf (ops.py:24-140): content [Nc][C], style [Ns][C], out [Nc][C].
  * eps: the reference functions' `eps` argument (wct_np: added inside the spectral gains,
- * default 1e-5; wct_tf: added to the covariance diagonal, default 1e-8); eps < 0 = default. */
+ * default 1e-5; wct_tf: added to the covariance diagonal, default 1e-8); eps < 0 = default.
+ * Cut-off: the reference keeps eigenvalues > 1e-5 (ops.py:68-69 / 112,125).  So does this path, with one refinement for
+ * covariances whose float32 rounding noise is ABOVE that absolute threshold (N < C pixels at feature scales from ~10 up: the
+ * exact zeros come out as +-1.5e-7 ||cov||): a covariance is positive semi-definite, its most negative computed eigenvalue -r
+ * measures that noise, and eigenvalues <= max(1e-5, 2 r) are dropped -- the outcome of the reference's formula in exact
+ * arithmetic, inside the band of kept counts its own float32 evaluation can land on (csrc/wct.hip spectral_cut). */
 int wct_transform(wct_ctx* ctx, const float* content, int Nc, const float* style, int Ns,
                   int C, float alpha, int mode, float eps, float* out,
                   int* sweeps_out /* [2] (content, style) or NULL: Jacobi sweeps used, > 0 when converged;

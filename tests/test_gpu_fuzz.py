@@ -277,6 +277,27 @@ def test_conv3x3_reduced_flop_kernel_random_shapes(ctx, h, w, cin, cout, relu, u
         assert np.array_equal(got[0], ctx.conv3x3_f16(x[0], wt, b, relu=relu, upsample=up, pool=pool, algo=2))
 
 
+@settings(max_examples=10 * FUZZ_SCALE, **COMMON)
+@given(c=st.sampled_from([64, 128, 256]), hc=st.integers(5, 18), wc=st.integers(5, 18), hs=st.integers(5, 18), ws=st.integers(5, 18),
+       patch=st.sampled_from([1, 3]), alpha=st.floats(0.1, 1.0), seed=st.integers(0, 10 ** 6))
+def test_style_swap_random_shapes(ctx, c, hc, wc, hs, ws, patch, alpha, seed):
+    """wct_style_swap (ops.py:145-278: whiten both sides, match every content patch to its best style patch by normalised correlation,
+    paste, colour) on random map sizes, N < C included.  The match is an argmax: a pixel may differ from the oracle's only inside the
+    footprint of a position the oracle itself decides by less than 1e-3 of the correlation (tests/test_gpu_ops.py::test_style_swap)."""
+    from wct_tf_amd import ops
+    from wct_tf_amd.weights import synthetic_features
+    fc = synthetic_features(seed, c, hc, wc, 1.5)
+    fs = synthetic_features(seed + 1, c, hs, ws, 1.5)
+    want, margins = oracle.wct_style_swap(fc, fs, alpha, patch, 1, return_margins=True)
+    got = ops.wct_style_swap(fc, fs, alpha, patch, 1, ctx=ctx)
+    assert got.shape == want.shape
+    diff = np.abs(got - want).max(-1).reshape(hc, wc) > 1e-3 * np.abs(want).max()
+    near = np.zeros(diff.shape, bool)
+    for y, x in zip(*np.nonzero(margins < 1e-3)):
+        near[y:y + patch, x:x + patch] = True
+    assert rel_err(got, want) < 1e-3 or not np.any(diff & ~near), (c, hc, wc, hs, ws, patch, alpha, seed, int((diff & ~near).sum()))
+
+
 @settings(max_examples=12 * FUZZ_SCALE, **COMMON)
 @given(hs=st.integers(1, 90), ws=st.integers(1, 90), ht=st.integers(1, 90), wt=st.integers(1, 90),
        seed=st.integers(0, 2 ** 31 - 1))

@@ -551,7 +551,7 @@ def test_style_swap(ctx, c, hc, wc, hs, ws, p, st):
     # error on these features: 2.4e-4, tools/probe/r06_swap_margin.py): a match the oracle itself decides by less than 1e-3 of the
     # correlation may legitimately go to the runner-up.  Round 6: quantified with the oracle's margins instead of "< 1 % of the
     # pixels" -- every pixel that differs must lie in the p x p footprint of such a near-tie position, and nowhere else.
-    diff = np.abs(got - want).max(-1) > 1e-3 * np.abs(want).max()
+    diff = np.abs(got - want).max(-1).reshape(want.shape[-3:-1]) > 1e-3 * np.abs(want).max()      # [hc][wc] (the maps carry a batch axis of 1)
     near = np.zeros(diff.shape, bool)
     for y, x in zip(*np.nonzero(margins < 1e-3)):
         near[y * st:y * st + p, x * st:x * st + p] = True
