@@ -271,7 +271,9 @@ def test_conv3x3_reduced_flop_kernel_random_shapes(ctx, h, w, cin, cout, relu, u
         if pool:
             emu, want32 = oracle.maxpool2x2_same(emu), oracle.maxpool2x2_same(want32)
         assert got[i].shape == want32.shape, (h, w, cin, cout, relu, up, pool, batch)
-        assert rel_err(got[i], emu) < 1e-4 and max_rel(got[i], emu) < 2e-3, (h, w, cin, cout, relu, up, pool, batch, i)
+        # (a handful of fp16 rounding flips -- up to 2^-10 of an element each -- weigh 1 / sqrt(n) in the norm of an n-element output:
+        #  a 2 x 2 image pooled to one pixel has 256 elements, and two flips read 1.2e-4 there)
+        assert rel_err(got[i], emu) < 1e-4 + 2e-3 / np.sqrt(emu.size) and max_rel(got[i], emu) < 2e-3, (h, w, cin, cout, relu, up, pool, batch, i)
         assert rel_err(got[i], want32) < 1.5e-3, (h, w, cin, cout, relu, up, pool, batch, i)
     if batch > 1:
         assert np.array_equal(got[0], ctx.conv3x3_f16(x[0], wt, b, relu=relu, upsample=up, pool=pool, algo=2))
