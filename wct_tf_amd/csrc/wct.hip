@@ -1260,6 +1260,7 @@ __global__ __launch_bounds__(256) void jacobi_gather_kernel(float* A, const floa
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+constexpr int JACOBI_ROWSUM_MAX = 1024;                // words of row sums per matrix (C <= 1024; see JACOBI_ROW_K below)
 // mat0 = index of the group's first matrix in the 2P batch; skipped style matrices start out `done`
 __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float* V, JacobiState* st, int C, int mat0, int shared_style, unsigned* rowsum) {
   __shared__ float red[4];
@@ -1270,7 +1271,7 @@ __global__ __launch_bounds__(256) void jacobi_init_kernel(const float* A, float*
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cc; i += (size_t)gridDim.x * blockDim.x)
       V[(size_t)m * cc + i] = (i / C == i % C) ? 1.f : 0.f;
   if (blockIdx.x == 0) {
-    for (int i = threadIdx.x; i < C; i += 256) rowsum[(size_t)m * 1024 + i] = 0u;      // (JACOBI_ROWSUM_MAX words per matrix: jacobi_resid_kernel)
+    for (int i = threadIdx.x; i < C; i += 256) rowsum[(size_t)m * JACOBI_ROWSUM_MAX + i] = 0u;      // (jacobi_resid_kernel adds, jacobi_check_kernel clears)
     float mx = 0.f;                          // NaN diagonals drop out of fmaxf; the pair kernels flag them
     if (!skip) for (int i = threadIdx.x; i < C; i += 256) mx = fmaxf(mx, fabsf(A[(size_t)m * cc + (size_t)i * C + i]));
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1322,7 +1323,7 @@ constexpr int JACOBI_RESID_STRIDE = 8;                 // floats per (matrix, ti
 // profiles/r06_fuzz_wide.txt).  Row sums: every tile adds its 64 row and 64 column sums into rowsum[m][C] as 2^-20 fixed point
 // with integer atomics (associative: the sums, and with them the sweep counts and every output bit, do not depend on the order),
 // jacobi_check_kernel takes the maximum, clears the words, and a matrix is done only if max_p rowsum_p / 2 < JACOBI_ROW_K tol^2 too.
-constexpr int JACOBI_ROWSUM_MAX = 1024;                // words per matrix (C <= 1024)
+// (a contribution is capped at 32 = 2^25 words: at most 2 x 16 tiles add to a row, so a word cannot wrap)
 constexpr float JACOBI_ROW_K = 8.f;
 constexpr float JACOBI_ROW_FIX = 1048576.f;            // 2^20
 struct JacobiCheckArgs {
